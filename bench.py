@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — batch exact-match search throughput (BASELINE.json metric) on N GPUs of one node.
+
+One "step" = one pass of the hot path over one batch: 1e7 uniform random DNA4 10-mers per GPU against a
+k=10 index of a 1e8-bp synthetic text (BASELINE.json configs[1]); inputs resident in HBM before the timed
+region; the index is replicated per GPU and every rank searches its own query shard (weak scaling, no
+data-path collective; per-rank totals are exchanged once after the timed region).
+
+Prints ONE JSON line on rank 0 (see the bench contract in the task / DESIGN.md §6).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=100_000_000, help="text length")
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--sigma", type=int, default=4)
+    ap.add_argument("--nq", type=int, default=10_000_000, help="queries per GPU per step")
+    ap.add_argument("--table", choices=["open", "dense", "auto"], default="open")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="queries in the CPU baseline sample")
+    ap.add_argument("--verify", type=int, default=20000, help="queries checked against the oracle after timing")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from kmer_index_amd import engine, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    def log(*a):
+        if rank == 0:
+            print("[bench]", *a, file=sys.stderr, flush=True)
+
+    t0 = time.time()
+    text = synth.ranks(1002, args.n, args.sigma)                      # identical on every rank
+    log(f"text n={args.n} sigma={args.sigma} generated in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    table = {"open": engine.TABLE_OPEN, "dense": engine.TABLE_DENSE, "auto": engine.TABLE_AUTO}[args.table]
+    idx = engine.Index(text, args.sigma, [args.k], table=table, device=local_rank)
+    info = idx.info()
+    log(f"index built+uploaded in {time.time() - t0:.1f}s: {info}")
+
+    # this rank's query shard: letters [rank*nq*m, (rank+1)*nq*m) of query stream 2002
+    m = args.k
+    nq = args.nq
+    qr_host = np.empty(nq * m, np.uint8)
+    chunk = 1 << 24
+    for s in range(0, nq * m, chunk):
+        e = min(nq * m, s + chunk)
+        z = synth.u64_stream(2002, e - s, rank * nq * m + s)
+        qr_host[s:e] = (((z >> np.uint64(32)) * np.uint64(args.sigma)) >> np.uint64(32)).astype(np.uint8)
+    qoff_host = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+    d_qr = torch.from_numpy(qr_host).to(dev)
+    d_qoff = torch.from_numpy(qoff_host.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+
+    stream = torch.cuda.current_stream().cuda_stream
+    res = engine.Result()
+
+    def step():
+        idx.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=stream, result=res)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    idx.stats_enable(True)
+    idx.stats_reset()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    stats = idx.stats()
+    idx.stats_enable(False)
+    counts = res.counts()
+
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_hits = torch.tensor([counts["n_hits"]], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t_hits, op=dist.ReduceOp.SUM)          # the one exchange: per-shard hit totals
+    elapsed = float(t_el.item())
+    total_hits = int(t_hits.item())
+
+    # ---- verification of a sample against the CPU oracle (after the timed region) ----
+    verified = None
+    cpu_baseline = None
+    if rank == 0:
+        from oracle import orc
+        nv = min(args.verify, nq)
+        hit_off, positions, status, kinds = res.host()
+        if world == 1 and not args.no_cpu_baseline:
+            t1 = time.time()
+            T = os.cpu_count() or 1
+            oidx = orc.Index(text, args.sigma, [args.k], n_threads=T)
+            log(f"oracle (CPU restatement) index built in {time.time() - t1:.1f}s")
+            ns = min(args.cpu_sample, nq)
+            t1 = time.perf_counter()
+            oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=T, keep_hits=False)
+            dt = time.perf_counter() - t1
+            cpu_baseline = {"value": round(ns / dt / 1e6, 4), "unit": "M queries/s", "cores": T, "kind": "port",
+                            "sample": f"first {ns} of the {nq} queries, same 1e8-bp text, search(q).to_vector() per query "
+                                      f"on the oracle's thread pool ({T} threads, std::unordered_map buckets), {dt:.1f}s wall"}
+            o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
+            verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
+            oidx.close()
+        else:
+            # no oracle index at this size: ground-truth a few queries by naive scan of the text prefix property
+            qi = np.repeat(np.arange(nv), np.diff(hit_off[:nv + 1]).astype(np.int64))
+            pos = positions[:int(hit_off[nv])].astype(np.int64)
+            ok = all(np.array_equal(text[pos + j], qr_host.reshape(-1, m)[qi, j]) for j in range(m))
+            verified = bool(ok)
+        if not verified:
+            log("VERIFICATION FAILED")
+
+    if rank == 0:
+        n_total_q = nq * world
+        ms_per_step = elapsed / args.steps * 1e3
+        value = n_total_q * args.steps / elapsed / 1e6
+        fill = stats.get("k_fill", {"launches": 0, "total_ms": 0.0})
+        fill_ms = fill["total_ms"] / max(fill["launches"], 1)
+        n_hits_rank = counts["n_hits"]
+        # algorithmic bytes: per query R = m + 16 + 4c, W = 8 + 4c.  k_fill moves the 4c + 4c part.
+        fill_bytes = 8.0 * n_hits_rank
+        job_bytes = float(nq) * (m + 16 + 8) + 8.0 * n_hits_rank
+        achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
+        kernels_ms = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items() if v["launches"]}
+        out = {
+            "metric": "M queries/sec, DNA4 k=10 exact-match batch search, 1e8-bp text",
+            "value": round(value, 3),
+            "unit": "M queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32/u64",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: DNA4 text {args.n} bp, k={args.k}, {nq} uniform random {m}-mer queries per GPU per step, "
+                                   f"materialised sorted position lists (to_vector), table={args.table}",
+                       "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
+                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated"},
+            "roofline": {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),
+                         "job_algorithmic_GBps": round(job_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                         "job_frac": round(job_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "cpu_baseline": cpu_baseline,
+            "kernels_avg_ms": kernels_ms,
+            "verified_vs_oracle": verified,
+        }
+        print(json.dumps(out), flush=True)
+    res.close()
+    idx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,188 @@
+/* kmx.h — C-ABI of the MI355X-native k-mer exact-match batch search engine.
+ *
+ * This is the drop-in boundary underneath the reference's C++ template surface
+ * (Clemapfel/kmer_index).  The reference has no FFI of its own; every entry point
+ * below names the reference interface it stands in for (file:line relative to the
+ * reference checkout).  The C++ host mirror in include/kmer_index_amd/ keeps the
+ * reference's class and function names and calls only these functions.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no exceptions cross the boundary: every call
+ *     returns a kmx_status and kmx_last_error() gives a thread-local message;
+ *   - letters are passed as alphabet RANKS, one byte per letter, exactly what
+ *     seqan3::to_rank yields for the reference's alphabet_t (kmer_index.hpp:59,128);
+ *   - positions are uint32_t text offsets (position_t = uint32_t, kmer_index.hpp:575);
+ *   - input buffers are borrowed for the duration of the call; results are owned by
+ *     the library until kmx_result_free;
+ *   - one kmx_index may be searched from several host threads at once (the
+ *     reference's search() is const, kmer_index.hpp:505) provided each call uses
+ *     its own stream and result handle;
+ *   - the engine needs the HIP runtime and a gfx950 device: there is no CPU path.
+ */
+#ifndef KMX_H
+#define KMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KMX_VERSION 1
+#define KMX_MAX_KS 32               /* number of k values one index may hold                      */
+#define KMX_QUERY_SIZE_RANGE 10000  /* kmer_index::_query_size_range, kmer_index.hpp:401          */
+#define KMX_SUBK_FANOUT_LIMIT 10000000ull /* sigma^(k-m) guard, kmer_index.hpp:119                */
+
+typedef enum kmx_status {
+    KMX_OK = 0,
+    KMX_ERR_INVALID_ARGUMENT = 1,  /* bad pointer / size / k (static_assert kmer_index.hpp:42-43) */
+    KMX_ERR_HIP = 2,               /* HIP runtime error (message has the HIP error string)       */
+    KMX_ERR_OUT_OF_MEMORY = 3,
+    KMX_ERR_NO_DEVICE = 4,         /* no gfx950 device visible: the engine never falls back       */
+    KMX_ERR_TOO_LARGE = 5          /* text too long for 32-bit positions (kmer_index.hpp:169-170) */
+} kmx_status;
+
+/* Per-query status (array returned by kmx_result_status).  QUERY_TOO_LONG and
+ * SUBK_FANOUT are the two places where the reference throws std::invalid_argument
+ * (kmer_index.hpp:507-509 and :119-122); EMPTY_QUERY is its assert at :195. */
+typedef enum kmx_query_status {
+    KMX_Q_OK = 0,
+    KMX_Q_TOO_LONG = 1,
+    KMX_Q_SUBK_FANOUT = 2,
+    KMX_Q_EMPTY_QUERY = 3,
+    KMX_Q_BAD_RANK = 4   /* a letter >= sigma: not representable in the reference's alphabet_t */
+} kmx_query_status;
+
+/* How a query was served (array returned by kmx_result_kinds). */
+typedef enum kmx_query_kind {
+    KMX_KIND_NONE = 0,     /* error status or a part missed: empty result (kmer_index.hpp:204,224,524)  */
+    KMX_KIND_EXACT = 1,    /* one bucket, bitmask bypassed (kmer_index.hpp:198-205, :529-530)           */
+    KMX_KIND_STITCH = 2,   /* candidates = first part's bucket + validity mask (:207-339, :532-555)     */
+    KMX_KIND_PREFIX = 3    /* m < k: every k-mer with this prefix + last-kmer fix-up (:115-148, :342-345) */
+} kmx_query_kind;
+
+typedef enum kmx_table_kind {
+    KMX_TABLE_AUTO = 0,    /* dense when sigma^k <= 4 * (n-k+1), else open addressing                   */
+    KMX_TABLE_OPEN = 1,    /* open-addressing {key, offset, count} slots, linear probing, load <= 0.5   */
+    KMX_TABLE_DENSE = 2    /* direct addressing: offsets[sigma^k + 1]                                   */
+} kmx_table_kind;
+
+typedef struct kmx_options {
+    uint32_t struct_size;  /* = sizeof(kmx_options)                                                     */
+    int32_t device;        /* HIP device ordinal; -1 = current device                                   */
+    uint32_t table_kind;   /* kmx_table_kind                                                            */
+    uint32_t n_threads;    /* host threads for the per-k flatten (kmer_index ctor's n_threads, :481)    */
+    uint32_t query_size_range; /* 0 = KMX_QUERY_SIZE_RANGE (extend_query_size_range, :498-502)          */
+    uint32_t keep_host_arena;  /* keep a host copy of the position arena (kmx_index_arena_host)         */
+    uint32_t reserved[2];
+} kmx_options;
+
+/* kmx_search_batch flags */
+#define KMX_SEARCH_DEFAULT 0u
+#define KMX_SEARCH_KEEP_MASKS 1u   /* keep candidate runs + compressed_bitset mask words for STITCH queries */
+#define KMX_SEARCH_COUNT_ONLY 2u   /* stop after hit_off (no position lists are materialised)              */
+
+typedef struct kmx_index kmx_index;
+typedef struct kmx_result kmx_result;
+
+/* Per-kernel timing collected with HIP events on the caller's stream. */
+#define KMX_N_KERNELS 16
+typedef struct kmx_kernel_stat {
+    const char* name;
+    uint64_t launches;
+    double total_ms;
+} kmx_kernel_stat;
+
+/* ---- construction: stands in for kmer::make_kmer_index<ks...>(text, n_threads)
+ *      (kmer_index.hpp:569-579) and the kmer_index constructor (:480-496), i.e. one
+ *      kmer_index_element::create per k (:154-179) plus choose_search_scheme (:407-476).
+ *      `ranks` holds n letters as ranks < sigma.  Requires 0 < k < 64/log2(sigma) for
+ *      every k (:42-43), n >= max k and n + max k - 1 < 2^32 (:169-170). */
+kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, const uint32_t* ks,
+                           uint32_t n_ks, const kmx_options* opts, kmx_index** out);
+void kmx_index_free(kmx_index* index);
+
+/* Introspection of the flattened index (sizes in bytes are device-resident bytes). */
+kmx_status kmx_index_info(const kmx_index* index, uint64_t* n, uint32_t* sigma, uint32_t* n_ks,
+                          uint32_t* ks /* KMX_MAX_KS */, uint32_t* table_kinds /* KMX_MAX_KS */,
+                          uint64_t* device_bytes);
+
+/* Planner tables — kmer_index::_optimal_nk_sum / _use_multi_search_scheme
+ * (kmer_index.hpp:404-405) as built by choose_search_scheme (:407-476).  Pure host
+ * code; usable without a device.  nk_off has range+1 entries into nk_flat; returns
+ * the number of flat entries through *n_flat (call with nk_flat = NULL to size). */
+kmx_status kmx_plan(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint8_t* use_multi,
+                    uint32_t* nk_off, uint32_t* nk_flat, uint64_t cap, uint64_t* n_flat);
+
+/* kmer::detail::fast_pow (fast_pow.hpp:46-93), including its "0 on exp >= 63" rule. */
+uint64_t kmx_fast_pow(uint64_t base, uint8_t exp);
+
+/* ---- search: stands in for kmer_index::search(std::vector<alphabet_t>&) const
+ *      (kmer_index.hpp:505-558) applied to a BATCH of queries, followed by
+ *      kmer_index_result::to_vector() (kmer_index_result.hpp:244-260) per query.
+ *      qranks: the queries' letters as ranks, concatenated; qoff[nq+1]: start of each
+ *      query in qranks (qoff[0] = 0).  Host-buffer form: copies the inputs to the
+ *      device, runs the device form on an internal stream, and leaves the result
+ *      ready for kmx_result_view. */
+kmx_status kmx_search_batch(const kmx_index* index, const uint8_t* qranks, const uint64_t* qoff,
+                            uint64_t nq, uint32_t flags, kmx_result** out);
+
+/* Device-buffer form: d_qranks / d_qoff are device pointers already resident in HBM,
+ * `stream` is a hipStream_t (NULL = the default stream).  All kernels are enqueued on
+ * `stream`; the call returns after the one host read-back it needs (per-kind counts
+ * and the hit total, 64 bytes) and with the fill kernels enqueued.  Passing a result
+ * from a previous call in *inout reuses its device buffers (no allocation in the
+ * steady state). */
+kmx_status kmx_search_batch_device(const kmx_index* index, const void* d_qranks, const void* d_qoff,
+                                   uint64_t nq, uint32_t flags, void* stream, kmx_result** inout);
+
+/* Result access.  Device views are valid after the call returns (in stream order);
+ * host views copy to pinned host memory on first use and synchronise the stream.
+ *   hit_off[nq+1]  : start of query q's hits in `positions` (uint64)
+ *   positions[...] : per query the ascending list of text offsets where it occurs —
+ *                    kmer_index_result::to_vector() (kmer_index_result.hpp:244-260)
+ *   status[nq]     : kmx_query_status (uint8)
+ *   kinds[nq]      : kmx_query_kind   (uint8) */
+kmx_status kmx_result_counts(const kmx_result* r, uint64_t* nq, uint64_t* n_hits, uint64_t* n_exact,
+                             uint64_t* n_stitch, uint64_t* n_prefix, uint64_t* n_error);
+kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_off,
+                                  const uint32_t** d_positions, const uint8_t** d_status);
+kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32_t** positions,
+                           const uint8_t** status, const uint8_t** kinds);
+
+/* KMX_SEARCH_KEEP_MASKS only — the reference's zero-copy result view
+ * (kmer_index_result.hpp:15-24: pointers to bucket vectors + a compressed_bitset).
+ * For a STITCH query q (kinds[q] == KMX_KIND_STITCH):
+ *   cand_src[q]   : arena index of its candidate run = the first part's bucket
+ *                   (kmer_index.hpp:272, :532), cand_count[q] ascending positions;
+ *   mask_base[q]  : index of its first word in mask_words; it owns
+ *                   cand_count[q]/64 + 1 words in compressed_bitset layout
+ *                   (compressed_bitset.hpp:9-105: bit i = word i>>6, bit i&63);
+ *                   bit i set <=> candidate i is a hit; padding bits are 0.
+ * Entries of other queries are undefined.  The arena itself is reachable on the
+ * host through kmx_index_arena_host when the index was built with keep_host_arena. */
+kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uint64_t** mask_words,
+                            const uint32_t** cand_count, const uint64_t** cand_src);
+kmx_status kmx_index_arena_host(const kmx_index* index, const uint32_t** arena, uint64_t* n_elems);
+
+void kmx_result_free(kmx_result* r);
+
+/* Timing of the kernels launched for this index since the last reset (HIP events on
+ * the stream each kernel ran on).  Enabled by kmx_stats_enable(index, 1). */
+kmx_status kmx_stats_enable(kmx_index* index, int enable);
+kmx_status kmx_stats_get(kmx_index* index, kmx_kernel_stat* stats /* KMX_N_KERNELS */, uint32_t* n);
+kmx_status kmx_stats_reset(kmx_index* index);
+
+/* Debug aid: 16 words of range-violation records written by -DKMX_CHECKED builds (word 0 = count;
+ * always 0 in a normal build). */
+kmx_status kmx_debug_words(const kmx_index* index, uint64_t* words16);
+
+const char* kmx_last_error(void);
+const char* kmx_status_string(kmx_status s);
+uint32_t kmx_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KMX_H */

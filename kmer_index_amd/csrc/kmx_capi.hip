@@ -1,0 +1,669 @@
+// C-ABI (include/kmx.h) over the gfx950 kernels: index upload, batch orchestration,
+// result views, per-kernel HIP-event timing.  Host C++ only; every device-side step
+// is a kernel from kmx_kernels.hip.  There is deliberately no CPU search path here:
+// without a device every search entry point fails with KMX_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kmx_host.h"
+#include "kmx_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+kmx_status fail(kmx_status st, const std::string& msg)
+{
+    g_err = msg;
+    return st;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e__ = (expr);                                                               \
+        if (e__ != hipSuccess) {                                                               \
+            kmx_status st__ = (e__ == hipErrorOutOfMemory) ? KMX_ERR_OUT_OF_MEMORY : KMX_ERR_HIP; \
+            if (e__ == hipErrorNoDevice || e__ == hipErrorInvalidDevice) st__ = KMX_ERR_NO_DEVICE; \
+            return fail(st__, std::string(#expr) + ": " + hipGetErrorString(e__));             \
+        }                                                                                      \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 16 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+struct HostBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    bool ensure(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        free(p);
+        p = malloc(bytes + 64);
+        cap = p ? bytes + 64 : 0;
+        return p != nullptr;
+    }
+    void release() { free(p); p = nullptr; cap = 0; }
+    template <typename T> T* as() const { return static_cast<T*>(p); }
+};
+
+enum KernelId {
+    K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK, K_COUNT
+};
+const char* const kKernelNames[K_COUNT] = {
+    "k_lookup", "k_scan(reduce+spine+down)", "k_partition", "k_fill", "k_validate", "k_compact",
+    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back"};
+
+struct Stats {
+    bool enabled = false;
+    std::mutex mu;
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    uint64_t launches[K_COUNT] = {};
+    double ms[K_COUNT] = {};
+
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    // resolve every finished pair (blocks on unfinished ones)
+    void drain()
+    {
+        for (auto& p : pending) {
+            (void)hipEventSynchronize(p.b);
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess) { ms[p.id] += t; launches[p.id] += 1; }
+            pool.push_back(p.a);
+            pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+    void destroy()
+    {
+        drain();
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+} // namespace
+
+struct kmx_index {
+    int device = 0;
+    uint64_t n = 0;
+    uint32_t sigma = 0;
+    uint32_t range = KMX_QUERY_SIZE_RANGE;
+    std::vector<uint32_t> ks;
+    std::vector<uint32_t> table_kinds;
+    std::vector<void*> allocs;          // device allocations owned by the index
+    uint64_t device_bytes = 0;
+    KmxIndexDev* d_index = nullptr;     // device copy of the header
+    unsigned long long* d_dbg = nullptr; // KMX_CHECKED violation records
+    std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
+    hipStream_t stream = nullptr;       // internal stream of the host-buffer search form
+    std::mutex host_call_mu;
+    Stats stats;
+};
+
+struct kmx_result {
+    const kmx_index* index = nullptr;   // identity only: never dereferenced after the search call returns
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t flags = 0;
+    uint64_t nq = 0, n_hits = 0, n_exact = 0, n_stitch = 0, n_prefix = 0, n_error = 0, n_none = 0;
+    uint64_t n_mask_words = 0;
+    // device
+    DevBuf src, cnt, c0, aux, key, kind, status, stitch_list, prefix_list, hit_off, bsum, ctr, tile_q, out,
+        mask_words, plen, poff, ptmp, in_qranks, in_qoff;
+    unsigned long long* h_ctr = nullptr;   // pinned
+    // host mirrors
+    HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src;
+    bool host_valid = false, host_masks_valid = false;
+
+    void release()
+    {
+        for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
+                          &tile_q, &out, &mask_words, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
+            b->release();
+        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src})
+            b->release();
+        if (h_ctr) (void)hipHostFree(h_ctr);
+        h_ctr = nullptr;
+    }
+};
+
+namespace {
+
+template <typename F>
+void timed(kmx_index* ix, int id, hipStream_t s, F&& launch)
+{
+    if (!ix->stats.enabled) { launch(); return; }
+    std::lock_guard<std::mutex> lock(ix->stats.mu);
+    hipEvent_t a = ix->stats.get(), b = ix->stats.get();
+    (void)hipEventRecord(a, s);
+    launch();
+    (void)hipEventRecord(b, s);
+    ix->stats.pending.push_back({id, a, b});
+}
+
+template <typename T>
+kmx_status upload(kmx_index* ix, const T* host, size_t count, const T** dev_out)
+{
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&p, bytes));
+    ix->allocs.push_back(p);
+    ix->device_bytes += bytes;
+    if (count) HIP_TRY(hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev_out = static_cast<const T*>(p);
+    return KMX_OK;
+}
+
+kmx_status check_device()
+{
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(KMX_ERR_NO_DEVICE, "no HIP device visible: the kmx engine has no CPU search path");
+    return KMX_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* kmx_last_error(void) { return g_err.c_str(); }
+
+const char* kmx_status_string(kmx_status s)
+{
+    switch (s) {
+    case KMX_OK: return "ok";
+    case KMX_ERR_INVALID_ARGUMENT: return "invalid argument";
+    case KMX_ERR_HIP: return "HIP runtime error";
+    case KMX_ERR_OUT_OF_MEMORY: return "out of device memory";
+    case KMX_ERR_NO_DEVICE: return "no device";
+    case KMX_ERR_TOO_LARGE: return "text too large for 32-bit positions";
+    }
+    return "unknown";
+}
+
+uint32_t kmx_version(void) { return KMX_VERSION; }
+
+uint64_t kmx_fast_pow(uint64_t base, uint8_t exp) { return kmx::fast_pow(base, exp); }
+
+kmx_status kmx_plan(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint8_t* use_multi, uint32_t* nk_off,
+                    uint32_t* nk_flat, uint64_t cap, uint64_t* n_flat)
+{
+    if (!ks || n_ks == 0 || n_ks > KMX_MAX_KS || range == 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_plan: bad ks / range");
+    for (uint32_t i = 0; i < n_ks; ++i)
+        if (ks[i] == 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_plan: k must be > 0");
+    std::vector<uint32_t> v(ks, ks + n_ks);
+    kmx::Plan p = kmx::make_plan(v, range);
+    uint64_t total = 0;
+    for (uint32_t q = 0; q < range; ++q) {
+        if (use_multi) use_multi[q] = p.use_multi[q];
+        if (nk_off) nk_off[q] = uint32_t(total);
+        for (uint32_t k : p.nk_sum[q]) {
+            if (nk_flat && total < cap) nk_flat[total] = k;
+            ++total;
+        }
+    }
+    if (nk_off) nk_off[range] = uint32_t(total);
+    if (n_flat) *n_flat = total;
+    return KMX_OK;
+}
+
+kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, const uint32_t* ks, uint32_t n_ks,
+                           const kmx_options* opts, kmx_index** out)
+{
+    if (!out) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: out is NULL");
+    *out = nullptr;
+    if (!ranks || !ks || n_ks == 0 || n_ks > KMX_MAX_KS)
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: need ranks and 1..KMX_MAX_KS values of k");
+    kmx_options o{};
+    o.device = -1;
+    if (opts) {
+        if (opts->struct_size != sizeof(kmx_options))
+            return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: options.struct_size mismatch");
+        o = *opts;
+    }
+    uint32_t kmax = 0;
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        if (!kmx::k_is_valid(sigma, ks[i]))
+            return fail(KMX_ERR_INVALID_ARGUMENT,
+                        "the hashspace for the current k cannot be represented with only a 64-bit integer. Please specify a valid k");
+        for (uint32_t j = 0; j < i; ++j)
+            if (ks[j] == ks[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: duplicate k");
+        kmax = std::max(kmax, ks[i]);
+    }
+    if (n < kmax) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: text shorter than the largest k");
+    if (n + kmax - 1 >= 0xFFFFFFFFull) return fail(KMX_ERR_TOO_LARGE, "your text is too large for this configuration");
+    const uint32_t range = o.query_size_range ? o.query_size_range : KMX_QUERY_SIZE_RANGE;
+    if (range > 65535 * 9u) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: query_size_range too large");
+
+    kmx_status st = check_device();
+    if (st != KMX_OK) return st;
+    int device = o.device;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    HIP_TRY(hipSetDevice(device));
+
+    // flatten every element on host threads (the constructor's thread pool, kmer_index.hpp:485-492)
+    std::vector<kmx::ElemImage> images(n_ks);
+    std::vector<std::string> errs(n_ks);
+    std::vector<char> oks(n_ks, 0);
+    {
+        uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(o.n_threads ? o.n_threads : std::thread::hardware_concurrency(), n_ks));
+        std::vector<std::thread> threads;
+        std::atomic<uint32_t> next{0};
+        for (uint32_t t = 0; t < T; ++t)
+            threads.emplace_back([&] {
+                for (;;) {
+                    uint32_t i = next.fetch_add(1);
+                    if (i >= n_ks) return;
+                    oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i]);
+                }
+            });
+        for (auto& t : threads) t.join();
+    }
+    for (uint32_t i = 0; i < n_ks; ++i)
+        if (!oks[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]);
+
+    auto* ix = new kmx_index();
+    ix->device = device;
+    ix->n = n;
+    ix->sigma = sigma;
+    ix->range = range;
+    ix->ks.assign(ks, ks + n_ks);
+    auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
+
+    KmxIndexDev h{};
+    h.n = n; h.sigma = sigma; h.n_ks = n_ks; h.kmax = kmax; h.range = range;
+    for (uint32_t j = 0; j < 64; ++j) {
+        // fast_pow(sigma, j); products that leave 64 bits are never reached by a valid k
+        // and are saturated so the fan-out guard (> 1e7) still fires
+        unsigned __int128 v = 1;
+        for (uint32_t t = 0; t < j; ++t) { v *= sigma; if (v > ~uint64_t(0)) { v = ~uint64_t(0); break; } }
+        h.pw[j] = uint64_t(v);
+    }
+    // arena = every element's positions back to back
+    uint64_t arena_elems = 0;
+    for (auto& im : images) arena_elems += im.npos;
+    {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, std::max<uint64_t>(arena_elems * 4, 16));
+        if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
+        ix->allocs.push_back(p);
+        ix->device_bytes += arena_elems * 4;
+        h.arena = static_cast<const uint32_t*>(p);
+    }
+    h.arena_elems = arena_elems;
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, 16 * 8) == hipSuccess) { (void)hipMemset(p, 0, 16 * 8); ix->allocs.push_back(p); h.dbg = static_cast<unsigned long long*>(p); ix->d_dbg = h.dbg; }
+    }
+    if (o.keep_host_arena) ix->host_arena.reserve(arena_elems);
+    uint64_t base = 0;
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        auto& im = images[i];
+        KmxElemDev& el = h.elems[i];
+        el.k = im.k; el.table_kind = im.table_kind; el.log2cap = im.log2cap; el.n_ukeys = uint32_t(im.ukeys.size());
+        el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos;
+        ix->table_kinds.push_back(im.table_kind);
+        hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.npos * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+        if (o.keep_host_arena) ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.end());
+        if ((st = upload(ix, im.offs.data(), im.offs.size(), &el.offs)) != KMX_OK) return bail(st);
+        if (im.table_kind == KMX_TABLE_OPEN) {
+            if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
+            if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
+        }
+        base += im.npos;
+        im = kmx::ElemImage();   // release host memory early
+    }
+    if ((st = upload(ix, ranks + (n - kmax), kmax, &h.tail)) != KMX_OK) return bail(st);
+    {
+        std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, range);
+        if ((st = upload(ix, plan.data(), plan.size(), &h.plan)) != KMX_OK) return bail(st);
+    }
+    {
+        const KmxIndexDev* d = nullptr;
+        if ((st = upload(ix, &h, 1, &d)) != KMX_OK) return bail(st);
+        ix->d_index = const_cast<KmxIndexDev*>(d);
+    }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("stream: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+    }
+    *out = ix;
+    return KMX_OK;
+}
+
+void kmx_index_free(kmx_index* ix)
+{
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    ix->stats.destroy();
+    if (ix->stream) (void)hipStreamDestroy(ix->stream);
+    for (void* p : ix->allocs) (void)hipFree(p);
+    delete ix;
+}
+
+kmx_status kmx_index_info(const kmx_index* ix, uint64_t* n, uint32_t* sigma, uint32_t* n_ks, uint32_t* ks,
+                          uint32_t* table_kinds, uint64_t* device_bytes)
+{
+    if (!ix) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_info: index is NULL");
+    if (n) *n = ix->n;
+    if (sigma) *sigma = ix->sigma;
+    if (n_ks) *n_ks = uint32_t(ix->ks.size());
+    for (size_t i = 0; i < ix->ks.size(); ++i) {
+        if (ks) ks[i] = ix->ks[i];
+        if (table_kinds) table_kinds[i] = ix->table_kinds[i];
+    }
+    if (device_bytes) *device_bytes = ix->device_bytes;
+    return KMX_OK;
+}
+
+kmx_status kmx_index_arena_host(const kmx_index* ix, const uint32_t** arena, uint64_t* n_elems)
+{
+    if (!ix || !arena) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_arena_host: NULL argument");
+    if (ix->host_arena.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "index was built without keep_host_arena");
+    *arena = ix->host_arena.data();
+    if (n_elems) *n_elems = ix->host_arena.size();
+    return KMX_OK;
+}
+
+// KMX_CHECKED builds: copies the 16 violation-record words (word 0 = count).
+kmx_status kmx_debug_words(const kmx_index* ix, uint64_t* words16)
+{
+    if (!ix || !words16 || !ix->d_dbg) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_debug_words: NULL argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(words16, ix->d_dbg, 16 * 8, hipMemcpyDeviceToHost));
+    return KMX_OK;
+}
+
+kmx_status kmx_stats_enable(kmx_index* ix, int enable)
+{
+    if (!ix) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_stats_enable: index is NULL");
+    std::lock_guard<std::mutex> lock(ix->stats.mu);
+    ix->stats.enabled = enable != 0;
+    return KMX_OK;
+}
+
+kmx_status kmx_stats_get(kmx_index* ix, kmx_kernel_stat* stats, uint32_t* n)
+{
+    if (!ix || !stats || !n) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_stats_get: NULL argument");
+    std::lock_guard<std::mutex> lock(ix->stats.mu);
+    ix->stats.drain();
+    for (int i = 0; i < K_COUNT; ++i) stats[i] = kmx_kernel_stat{kKernelNames[i], ix->stats.launches[i], ix->stats.ms[i]};
+    *n = K_COUNT;
+    return KMX_OK;
+}
+
+kmx_status kmx_stats_reset(kmx_index* ix)
+{
+    if (!ix) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_stats_reset: index is NULL");
+    std::lock_guard<std::mutex> lock(ix->stats.mu);
+    ix->stats.drain();
+    for (int i = 0; i < K_COUNT; ++i) { ix->stats.launches[i] = 0; ix->stats.ms[i] = 0; }
+    return KMX_OK;
+}
+
+kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, const void* d_qoff, uint64_t nq,
+                                   uint32_t flags, void* stream, kmx_result** inout)
+{
+    if (!cix || !inout) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: NULL argument");
+    if (nq && (!d_qranks || !d_qoff)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: NULL query buffers");
+    if (nq >= 0xFFFFFFFFull) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: at most 2^32-2 queries per batch");
+    kmx_index* ix = const_cast<kmx_index*>(cix);
+    HIP_TRY(hipSetDevice(ix->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const uint8_t* qr = static_cast<const uint8_t*>(d_qranks);
+    const uint64_t* qo = static_cast<const uint64_t*>(d_qoff);
+
+    kmx_result* r = *inout;
+    if (!r) { r = new kmx_result(); *inout = r; }
+    r->index = ix;
+    r->device = ix->device;
+    r->stream = s;
+    (void)hipGetLastError();   // do not inherit a stale error from an earlier, unrelated call
+    r->flags = flags;
+    r->nq = nq;
+    r->n_hits = r->n_exact = r->n_stitch = r->n_prefix = r->n_error = r->n_none = r->n_mask_words = 0;
+    r->host_valid = r->host_masks_valid = false;
+    if (!r->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->h_ctr), KMX_CTR_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
+    HIP_TRY(r->hit_off.ensure((nq + 1) * 8));
+    if (nq == 0) {
+        HIP_TRY(hipMemsetAsync(r->hit_off.p, 0, 8, s));
+        return KMX_OK;
+    }
+    HIP_TRY(r->src.ensure(nq * 8));
+    HIP_TRY(r->cnt.ensure(nq * 4));
+    HIP_TRY(r->c0.ensure(nq * 4));
+    HIP_TRY(r->aux.ensure(nq * 8));
+    HIP_TRY(r->key.ensure(nq * 8));
+    HIP_TRY(r->kind.ensure(nq));
+    HIP_TRY(r->status.ensure(nq));
+    HIP_TRY(r->stitch_list.ensure(nq * 4));
+    HIP_TRY(r->prefix_list.ensure(nq * 4));
+    HIP_TRY(r->bsum.ensure(kmx::scan_blocks(nq) * 8));
+    HIP_TRY(r->ctr.ensure(KMX_CTR_COUNT * sizeof(unsigned long long)));
+    kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
+                     r->key.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
+                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>()};
+    auto* ctr = r->ctr.as<unsigned long long>();
+    const KmxIndexDev* dix = ix->d_index;
+
+    HIP_TRY(hipMemsetAsync(ctr, 0, KMX_CTR_COUNT * sizeof(unsigned long long), s));
+    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr); });
+    // speculative scan: already final when the batch holds no STITCH query
+    timed(ix, K_SCAN, s, [&] {
+        kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
+    });
+    HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    r->n_stitch = r->h_ctr[KMX_CTR_STITCH];
+    r->n_prefix = r->h_ctr[KMX_CTR_PREFIX];
+    r->n_error = r->h_ctr[KMX_CTR_ERROR];
+    r->n_none = r->h_ctr[KMX_CTR_NONE];
+    r->n_mask_words = r->h_ctr[KMX_CTR_MASK_WORDS];
+    r->n_exact = nq - r->n_stitch - r->n_prefix - r->n_error - r->n_none;
+    const uint64_t prefix_elems = r->h_ctr[KMX_CTR_PREFIX_ELEMS];
+    const uint64_t max_runs = r->h_ctr[KMX_CTR_MAX_RUNS];
+
+    if (r->n_stitch) {
+        HIP_TRY(r->mask_words.ensure(r->n_mask_words * 8));
+        timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, qr, qo, d, r->n_stitch, r->mask_words.as<uint64_t>()); });
+        timed(ix, K_SCAN, s, [&] {
+            kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
+        });
+        HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    r->n_hits = r->h_ctr[KMX_CTR_TOTAL_HITS];
+    if (flags & KMX_SEARCH_COUNT_ONLY) return KMX_OK;
+
+    const uint64_t total = r->n_hits;
+    if (total == 0) return KMX_OK;
+    const uint64_t tile = kmx::fill_tile();
+    const uint64_t n_tiles = (total + tile - 1) / tile;
+    if (n_tiles >= 0x7FFFFFFFull) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: result too large, split the batch");
+    HIP_TRY(r->out.ensure(total * 4));
+    HIP_TRY(r->tile_q.ensure((n_tiles + 1) * 4));
+    uint32_t* out = r->out.as<uint32_t>();
+    const uint64_t* hit_off = r->hit_off.as<uint64_t>();
+    timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, n_tiles, r->tile_q.as<uint32_t>()); });
+    timed(ix, K_FILL, s, [&] { kmx::launch_fill(s, dix, hit_off, r->tile_q.as<uint32_t>(), total, n_tiles, d, out); });
+    if (r->n_stitch)
+        timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, dix, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
+
+    if (r->n_prefix && max_runs > 1 && prefix_elems > 0) {
+        // merge the per-key runs of every PREFIX slice into one ascending list
+        const uint64_t np = r->n_prefix;
+        HIP_TRY(r->plen.ensure(np * 4));
+        HIP_TRY(r->poff.ensure((np + 1) * 8));
+        HIP_TRY(r->ptmp.ensure(prefix_elems * 4));
+        HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(np), kmx::scan_blocks(nq)) * 8));
+        timed(ix, K_PREFIX_LEN, s, [&] { kmx::launch_prefix_len(s, d, np, r->plen.as<uint32_t>()); });
+        timed(ix, K_SCAN, s, [&] {
+            kmx::launch_scan(s, r->plen.as<uint32_t>(), np, r->bsum.as<uint64_t>(), r->poff.as<uint64_t>(), ctr + KMX_CTR_PREFIX_TOTAL);
+        });
+        uint32_t passes = 0;
+        while ((uint64_t(1) << passes) < max_runs) ++passes;
+        int src_is_out = 1;
+        for (uint32_t p = 0; p < passes; ++p) {
+            timed(ix, K_MERGE_PASS, s, [&] {
+                kmx::launch_merge_pass(s, dix, qr, qo, d, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out,
+                                       r->ptmp.as<uint32_t>(), p, src_is_out);
+            });
+            src_is_out = !src_is_out;
+        }
+        if (!src_is_out)
+            timed(ix, K_COPY_BACK, s, [&] {
+                kmx::launch_prefix_copy_back(s, d, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out, r->ptmp.as<uint32_t>());
+            });
+    }
+    HIP_TRY(hipGetLastError());
+    return KMX_OK;
+}
+
+kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
+                            uint32_t flags, kmx_result** out)
+{
+    if (!cix || !out) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL argument");
+    if (nq && (!qranks || !qoff)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL query buffers");
+    if (nq && qoff[0] != 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: qoff[0] must be 0");
+    for (uint64_t i = 0; i < nq; ++i)
+        if (qoff[i + 1] < qoff[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: qoff must be non-decreasing");
+    kmx_index* ix = const_cast<kmx_index*>(cix);
+    std::lock_guard<std::mutex> lock(ix->host_call_mu);
+    HIP_TRY(hipSetDevice(ix->device));
+    kmx_result* r = *out ? *out : new kmx_result();
+    *out = r;
+    const uint64_t n_letters = nq ? qoff[nq] : 0;
+    HIP_TRY(r->in_qranks.ensure(std::max<uint64_t>(n_letters, 1)));
+    HIP_TRY(r->in_qoff.ensure((nq + 1) * 8));
+    if (n_letters) HIP_TRY(hipMemcpyAsync(r->in_qranks.p, qranks, n_letters, hipMemcpyHostToDevice, ix->stream));
+    if (nq) HIP_TRY(hipMemcpyAsync(r->in_qoff.p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
+    kmx_status st = kmx_search_batch_device(ix, r->in_qranks.p, r->in_qoff.p, nq, flags, ix->stream, out);
+    if (st != KMX_OK) return st;
+    HIP_TRY(hipStreamSynchronize(ix->stream));
+    return KMX_OK;
+}
+
+kmx_status kmx_result_counts(const kmx_result* r, uint64_t* nq, uint64_t* n_hits, uint64_t* n_exact, uint64_t* n_stitch,
+                             uint64_t* n_prefix, uint64_t* n_error)
+{
+    if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_counts: result is NULL");
+    if (nq) *nq = r->nq;
+    if (n_hits) *n_hits = r->n_hits;
+    if (n_exact) *n_exact = r->n_exact;
+    if (n_stitch) *n_stitch = r->n_stitch;
+    if (n_prefix) *n_prefix = r->n_prefix;
+    if (n_error) *n_error = r->n_error;
+    return KMX_OK;
+}
+
+kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_off, const uint32_t** d_positions,
+                                  const uint8_t** d_status)
+{
+    if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: result is NULL");
+    if (d_hit_off) *d_hit_off = r->hit_off.as<uint64_t>();
+    if (d_positions) *d_positions = r->out.as<uint32_t>();
+    if (d_status) *d_status = r->status.as<uint8_t>();
+    return KMX_OK;
+}
+
+kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32_t** positions, const uint8_t** status,
+                           const uint8_t** kinds)
+{
+    if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view: result is NULL");
+    if (!r->host_valid) {
+        HIP_TRY(hipSetDevice(r->device));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
+        if (!r->h_hit_off.ensure((r->nq + 1) * 8) || !r->h_status.ensure(std::max<uint64_t>(r->nq, 1)) ||
+            !r->h_kinds.ensure(std::max<uint64_t>(r->nq, 1)) || !r->h_positions.ensure(std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
+            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_view: host allocation failed");
+        HIP_TRY(hipMemcpy(r->h_hit_off.p, r->hit_off.p, (r->nq + 1) * 8, hipMemcpyDeviceToHost));
+        if (r->nq) {
+            HIP_TRY(hipMemcpy(r->h_status.p, r->status.p, r->nq, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_kinds.p, r->kind.p, r->nq, hipMemcpyDeviceToHost));
+        }
+        if (have_pos) HIP_TRY(hipMemcpy(r->h_positions.p, r->out.p, r->n_hits * 4, hipMemcpyDeviceToHost));
+        r->host_valid = true;
+    }
+    if (hit_off) *hit_off = r->h_hit_off.as<uint64_t>();
+    if (positions) *positions = ((r->flags & KMX_SEARCH_COUNT_ONLY) || !r->n_hits) ? nullptr : r->h_positions.as<uint32_t>();
+    if (status) *status = r->h_status.as<uint8_t>();
+    if (kinds) *kinds = r->h_kinds.as<uint8_t>();
+    return KMX_OK;
+}
+
+kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uint64_t** mask_words,
+                            const uint32_t** cand_count, const uint64_t** cand_src)
+{
+    if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: result is NULL");
+    if (!(r->flags & KMX_SEARCH_KEEP_MASKS)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: search ran without KMX_SEARCH_KEEP_MASKS");
+    if (!r->host_masks_valid) {
+        HIP_TRY(hipSetDevice(r->device));
+        HIP_TRY(hipStreamSynchronize(r->stream));
+        const uint64_t nq1 = std::max<uint64_t>(r->nq, 1);
+        if (!r->h_mask_base.ensure(nq1 * 8) || !r->h_cand_count.ensure(nq1 * 4) || !r->h_cand_src.ensure(nq1 * 8) ||
+            !r->h_mask_words.ensure(std::max<uint64_t>(r->n_mask_words, 1) * 8))
+            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_masks: host allocation failed");
+        if (r->nq) {
+            HIP_TRY(hipMemcpy(r->h_mask_base.p, r->aux.p, r->nq * 8, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_cand_count.p, r->c0.p, r->nq * 4, hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(r->h_cand_src.p, r->src.p, r->nq * 8, hipMemcpyDeviceToHost));
+        }
+        if (r->n_mask_words) HIP_TRY(hipMemcpy(r->h_mask_words.p, r->mask_words.p, r->n_mask_words * 8, hipMemcpyDeviceToHost));
+        r->host_masks_valid = true;
+    }
+    if (mask_base) *mask_base = r->h_mask_base.as<uint64_t>();
+    if (mask_words) *mask_words = r->h_mask_words.as<uint64_t>();
+    if (cand_count) *cand_count = r->h_cand_count.as<uint32_t>();
+    if (cand_src) *cand_src = r->h_cand_src.as<uint64_t>();
+    return KMX_OK;
+}
+
+void kmx_result_free(kmx_result* r)
+{
+    if (!r) return;
+    if (r->index) (void)hipSetDevice(r->device);
+    r->release();
+    delete r;
+}
+
+} // extern "C"

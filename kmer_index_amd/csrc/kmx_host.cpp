@@ -1,0 +1,198 @@
+#include "kmx_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace kmx {
+
+// kmer::detail::fast_pow (fast_pow.hpp:46-93): square-and-multiply over the
+// significant bits of exp; exp >= 63 is treated as overflow and yields 0 (1 when
+// base == 1) — including exp == 63 itself (fast_pow.hpp:19).
+uint64_t fast_pow(uint64_t base, uint8_t exp)
+{
+    if (exp >= 63) return base == 1 ? 1 : 0;
+    uint64_t result = 1;
+    while (exp) {
+        if (exp & 1) result *= base;
+        exp >>= 1;
+        if (exp) base *= base;
+    }
+    return result;
+}
+
+bool k_is_valid(uint32_t sigma, uint32_t k)
+{
+    if (sigma < 2 || sigma > 256 || k == 0) return false;
+    return double(k) < 64.0 / std::log2(double(sigma));   // kmer_index.hpp:42
+}
+
+Plan make_plan(const std::vector<uint32_t>& ks_in, uint32_t range)
+{
+    Plan p;
+    p.use_multi.assign(range, 0);
+    p.nk_sum.assign(range, {});
+    std::vector<uint32_t> all_ks(ks_in);
+    std::sort(all_ks.begin(), all_ks.end(), [](uint32_t a, uint32_t b) { return a > b; });   // :410
+    std::vector<uint32_t> high_ks;
+    for (uint32_t k : all_ks)
+        if (k >= 9) high_ks.push_back(k);                                                      // :412-415
+    for (uint32_t k : high_ks)                                                                 // :421-425
+        if (k < range) { p.nk_sum[k] = {k}; p.use_multi[k] = 1; }
+    for (uint64_t q = uint64_t(all_ks.front()) + 1; q < range; ++q) {                          // :427-443
+        for (uint32_t k : high_ks) {
+            if (!p.nk_sum[q - k].empty()) {
+                p.nk_sum[q] = p.nk_sum[q - k];
+                p.nk_sum[q].push_back(k);
+                p.use_multi[q] = 1;
+                break;
+            }
+        }
+    }
+    for (uint64_t q = 0; q < range; ++q) {                                                     // :445-475
+        if (!p.nk_sum[q].empty()) continue;
+        uint32_t best = all_ks.front();
+        if (q < all_ks.front()) {
+            // smallest k >= q (:450-461)
+            for (uint32_t k : all_ks)
+                if (q <= k && (k - q < best - q)) best = k;
+        } else {
+            // k with the smallest padding ceil(q/k)*k - q, first one in descending
+            // order wins; the reference evaluates this in float (:468-469)
+            for (uint32_t k : all_ks) {
+                float pad_k = std::ceil(float(q) / float(k)) * float(k) - float(q);
+                float pad_b = std::ceil(float(q) / float(best)) * float(best) - float(q);
+                if (pad_k < pad_b) best = k;
+            }
+        }
+        p.nk_sum[q] = {best};
+    }
+    return p;
+}
+
+std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uint32_t range)
+{
+    Plan p = make_plan(ks, range);
+    auto elem_of = [&](uint32_t k) -> uint8_t {
+        for (size_t i = 0; i < ks.size(); ++i)
+            if (ks[i] == k) return uint8_t(i);
+        return 0;
+    };
+    std::vector<KmxPlanEntry> out(range);
+    for (uint32_t q = 0; q < range; ++q) {
+        KmxPlanEntry e{};
+        const auto& sum = p.nk_sum[q];
+        // kmer_index.hpp:512: the multi scheme is used only when the table says so
+        // AND more than one k is instantiated.  Entries of the DP chain keep their
+        // MULTI form even when they are a single summand, so that chains can be
+        // walked; a 1-summand MULTI entry is served as an exact lookup (:529-530).
+        if (p.use_multi[q] && ks.size() > 1) {
+            e.scheme = KMX_SCHEME_MULTI;
+            e.elem = elem_of(sum.back());
+            e.nparts = uint16_t(sum.size());
+        } else {
+            e.scheme = KMX_SCHEME_SINGLE;
+            e.elem = elem_of(sum.at(0));
+            e.nparts = 1;
+        }
+        out[q] = e;
+    }
+    return out;
+}
+
+static uint32_t ceil_log2_u64(uint64_t v)
+{
+    uint32_t l = 0;
+    while ((uint64_t(1) << l) < v) ++l;
+    return l;
+}
+
+static void build_slots(ElemImage& im)
+{
+    uint64_t u = im.ukeys.size();
+    im.log2cap = std::max<uint32_t>(4, ceil_log2_u64(2 * std::max<uint64_t>(u, 1)));   // load <= 0.5
+    uint64_t cap = uint64_t(1) << im.log2cap;
+    im.slots.assign(cap, KmxSlot{0, 0, 0});
+    for (uint64_t i = 0; i < u; ++i) {
+        uint64_t s = slot_hash(im.ukeys[i], im.log2cap);
+        while (im.slots[s].cnt != 0) s = (s + 1) & (cap - 1);   // linear probing
+        im.slots[s] = KmxSlot{im.ukeys[i], im.offs[i], im.offs[i + 1] - im.offs[i]};
+    }
+}
+
+bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t k, uint32_t table_kind,
+                     ElemImage& im, std::string& err)
+{
+    if (!k_is_valid(sigma, k)) { err = "k must satisfy 0 < k < 64 / log2(sigma)"; return false; }
+    if (n < k) { err = "text shorter than k"; return false; }
+    if (n + k - 1 >= 0xFFFFFFFFull) { err = "your text is too large for this configuration"; return false; }   // :169-170
+    im = ElemImage();
+    im.k = k;
+    im.npos = n - k + 1;
+    im.n_keys = fast_pow(sigma, uint8_t(k));
+    const uint64_t HIST_MAX = uint64_t(1) << 30;
+    if (table_kind == KMX_TABLE_AUTO)
+        table_kind = (im.n_keys <= 4 * im.npos && im.n_keys <= HIST_MAX) ? KMX_TABLE_DENSE : KMX_TABLE_OPEN;
+    if (table_kind == KMX_TABLE_DENSE && im.n_keys > HIST_MAX) {
+        err = "dense table requested but sigma^k exceeds 2^30 keys";
+        return false;
+    }
+    im.table_kind = table_kind;
+    im.positions.resize(im.npos);
+    const uint64_t top = fast_pow(sigma, uint8_t(k - 1));
+
+    auto first_hash = [&]() {
+        uint64_t h = 0;
+        for (uint32_t i = 0; i < k; ++i) h = h * sigma + ranks[i];   // == sum r_i * sigma^(k-i-1), kmer_index.hpp:56-73
+        return h;
+    };
+
+    if (im.n_keys <= HIST_MAX) {
+        // counting sort by hash; stable, so positions ascend inside a group
+        std::vector<uint32_t> start(im.n_keys + 1, 0);
+        uint64_t h = first_hash();
+        for (uint64_t i = 0;; ++i) {
+            ++start[h + 1];
+            if (i + 1 >= im.npos) break;
+            h = (h - uint64_t(ranks[i]) * top) * sigma + ranks[i + k];
+        }
+        for (uint64_t j = 0; j < im.n_keys; ++j) start[j + 1] += start[j];
+        std::vector<uint32_t> cursor(start.begin(), start.end() - 1);
+        h = first_hash();
+        for (uint64_t i = 0;; ++i) {
+            im.positions[cursor[h]++] = uint32_t(i);
+            if (i + 1 >= im.npos) break;
+            h = (h - uint64_t(ranks[i]) * top) * sigma + ranks[i + k];
+        }
+        if (table_kind == KMX_TABLE_DENSE) {
+            im.offs.swap(start);
+        } else {
+            im.offs.push_back(0);
+            for (uint64_t j = 0; j < im.n_keys; ++j)
+                if (start[j + 1] != start[j]) { im.ukeys.push_back(j); im.offs.push_back(start[j + 1]); }
+            build_slots(im);
+        }
+    } else {
+        // key space too large for a histogram: sort (hash, position) pairs
+        std::vector<std::pair<uint64_t, uint32_t>> pairs(im.npos);
+        uint64_t h = first_hash();
+        for (uint64_t i = 0;; ++i) {
+            pairs[i] = {h, uint32_t(i)};
+            if (i + 1 >= im.npos) break;
+            h = (h - uint64_t(ranks[i]) * top) * sigma + ranks[i + k];
+        }
+        std::sort(pairs.begin(), pairs.end());
+        im.offs.push_back(0);
+        for (uint64_t i = 0; i < im.npos; ++i) {
+            im.positions[i] = pairs[i].second;
+            if (i + 1 == im.npos || pairs[i + 1].first != pairs[i].first) {
+                im.ukeys.push_back(pairs[i].first);
+                im.offs.push_back(uint32_t(i + 1));
+            }
+        }
+        build_slots(im);
+    }
+    return true;
+}
+
+} // namespace kmx

@@ -1,0 +1,48 @@
+// Host-side pieces of the engine: fast_pow, the planner (choose_search_scheme)
+// and the flatten of one text into per-k position arrays + tables.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+#include "kmx_types.h"
+
+namespace kmx {
+
+uint64_t fast_pow(uint64_t base, uint8_t exp);
+
+// kmer_index::choose_search_scheme (kmer_index.hpp:407-476).
+struct Plan {
+    std::vector<uint8_t> use_multi;               // _use_multi_search_scheme
+    std::vector<std::vector<uint32_t>> nk_sum;    // _optimal_nk_sum
+};
+Plan make_plan(const std::vector<uint32_t>& ks, uint32_t range);
+// Device form of the plan for an index holding `ks` (template order).
+std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uint32_t range);
+
+// Host image of one flattened kmer_index_element.
+struct ElemImage {
+    uint32_t k = 0;
+    uint32_t table_kind = 0;
+    uint32_t log2cap = 0;
+    uint64_t n_keys = 0;
+    uint64_t npos = 0;
+    std::vector<uint32_t> positions;   // npos entries, grouped by hash
+    std::vector<uint32_t> offs;        // dense: n_keys + 1; open: ukeys.size() + 1
+    std::vector<uint64_t> ukeys;       // open only
+    std::vector<KmxSlot> slots;        // open only
+};
+
+// Builds the image of one element — the work of kmer_index_element::create
+// (kmer_index.hpp:154-179).  Returns false and sets err on invalid parameters.
+bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t k, uint32_t table_kind,
+                     ElemImage& out, std::string& err);
+
+// static_assert(k > 0 and k < 64 / log2(sigma)) of kmer_index.hpp:42-43.
+bool k_is_valid(uint32_t sigma, uint32_t k);
+
+inline uint64_t slot_hash(uint64_t key, uint32_t log2cap)
+{
+    return log2cap ? (key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap) : 0;
+}
+
+} // namespace kmx

@@ -1,0 +1,46 @@
+// Launch interface of the gfx950 kernels (kmx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kmx_types.h"
+
+#ifndef KMX_FILL_E
+#define KMX_FILL_E 8   // output slots per thread in k_fill (tile = 256 * KMX_FILL_E slots)
+#endif
+
+namespace kmx {
+
+// Per-query descriptor arrays (structure of arrays, all device pointers).
+struct QueryDesc {
+    uint64_t* src;          // arena index of the run that feeds the query (bucket / prefix slice / candidates)
+    uint32_t* cnt;          // number of hits (STITCH: written by k_validate)
+    uint32_t* c0;           // STITCH: number of candidates; PREFIX: number of runs in the slice
+    uint64_t* aux;          // STITCH: index of the first mask word; PREFIX: last-kmer bits (bit j <-> position n-j)
+    uint64_t* key;          // PREFIX: key index of the first run (offs + key bounds the runs)
+    uint8_t* kind;          // kmx_query_kind
+    uint8_t* status;        // kmx_query_status
+    uint32_t* stitch_list;  // indices of the STITCH queries (arbitrary order)
+    uint32_t* prefix_list;  // indices of the PREFIX queries (arbitrary order)
+};
+
+void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr);
+void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words);
+uint64_t scan_blocks(uint64_t n);
+void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
+                 unsigned long long* total_out);
+uint64_t fill_tile();
+void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t n_tiles, uint32_t* tile_q);
+void launch_fill(hipStream_t s, const KmxIndexDev* ix, const uint64_t* hit_off, const uint32_t* tile_q,
+                 uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out);
+void launch_compact(hipStream_t s, const KmxIndexDev* ix, const QueryDesc& d, uint64_t n_stitch,
+                    const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out);
+void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen);
+void launch_merge_pass(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+                       const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
+                       const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass, int src_is_out);
+void launch_prefix_copy_back(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff,
+                             uint64_t p_total, const uint64_t* hit_off, uint32_t* out, const uint32_t* tmp);
+
+} // namespace kmx

@@ -1,0 +1,848 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels of the batch search path.
+//
+// Pipeline for one batch (launch order; [..] only when such queries exist):
+//   k_lookup        one query per lane: rank-hash (kmer_index.hpp:56-73), planner
+//                   lookup (:512-518), bucket probe (:76-84), sub-k prefix range +
+//                   last-kmer fix-up (:115-148) -> per-query descriptor
+//  [k_validate]     one wave per STITCH query: cross-reference of the parts' buckets
+//                   (:270-298, :532-555) -> compressed_bitset mask words via ballot
+//   k_scan_*        exclusive scan of the per-query hit counts -> hit_off
+//   k_partition     first query of every output tile
+//   k_fill          output-centric copy of bucket runs -> to_vector() lists
+//  [k_compact]      STITCH: mask-word decode, popcount prefix compaction
+//  [k_merge_pass*]  PREFIX: merge of the per-key runs into one ascending list (the
+//                   std::sort of kmer_index_result.hpp:258)
+//
+// All arithmetic is unsigned integer; no MFMA.  The kernels are HBM / latency
+// bound: see DESIGN.md for bytes per unit and the roofline of each.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "kmx_kernels.h"
+
+#define KMX_BLOCK 256
+#define KMX_WAVE 64
+
+namespace kmx {
+
+// ---------------------------------------------------------------------------
+// small device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (KMX_WAVE - 1); }
+
+struct Run {
+    uint64_t src;   // arena index of the run's first position
+    uint32_t cnt;
+};
+
+__device__ __forceinline__ uint64_t slot_hash_dev(uint64_t key, uint32_t log2cap)
+{
+    return log2cap ? (key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap) : 0;
+}
+
+// at(hash) — kmer_index.hpp:76-84: the bucket of one rank-hash, or cnt == 0.
+__device__ __forceinline__ Run probe(const KmxElemDev* __restrict__ el, uint64_t h)
+{
+    Run r;
+    if (el->table_kind == KMX_TABLE_DENSE) {
+        const uint32_t* __restrict__ offs = el->offs;
+        uint32_t a = offs[h], b = offs[h + 1];
+        r.src = el->arena_base + a;
+        r.cnt = b - a;
+        return r;
+    }
+    const KmxSlot* __restrict__ slots = el->slots;
+    const uint64_t mask = (uint64_t(1) << el->log2cap) - 1;
+    uint64_t s = slot_hash_dev(h, el->log2cap);
+    for (;;) {
+        // one 16-byte slot: {key, off, cnt}
+        const ulonglong2 raw = *reinterpret_cast<const ulonglong2*>(slots + s);
+        uint32_t off = uint32_t(raw.y), cnt = uint32_t(raw.y >> 32);
+        if (cnt == 0) { r.src = 0; r.cnt = 0; return r; }
+        if (raw.x == h) { r.src = el->arena_base + off; r.cnt = cnt; return r; }
+        s = (s + 1) & mask;
+    }
+}
+
+// first index i in [0, n) with a[i] >= x (n if none)
+template <typename T>
+__device__ __forceinline__ uint64_t lower_bound_dev(const T* __restrict__ a, uint64_t n, T x)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+// first index i in [0, n) with a[i] > x (n if none)
+template <typename T>
+__device__ __forceinline__ uint64_t upper_bound_dev(const T* __restrict__ a, uint64_t n, T x)
+{
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] <= x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// rank-hash of `len` letters by Horner's rule; equals sum r_i * sigma^(len-i-1)
+// (kmer_index.hpp:56-73) because k < 64/log2(sigma) rules out wrap-around.
+// Returns false when a letter is not a valid rank.
+__device__ __forceinline__ bool rank_hash(const uint8_t* __restrict__ q, uint32_t len, uint32_t sigma, uint64_t& h)
+{
+    uint64_t acc = 0;
+    bool ok = true;
+    for (uint32_t i = 0; i < len; ++i) {
+        uint32_t r = q[i];
+        ok &= r < sigma;
+        acc = acc * sigma + r;
+    }
+    h = acc;
+    return ok;
+}
+
+// ---------------------------------------------------------------------------
+// k_lookup — one query per lane.
+// ---------------------------------------------------------------------------
+struct BlockCounters {
+    unsigned int n_stitch, n_prefix, n_error, n_none;
+    unsigned long long words, pelems;
+    unsigned int max_runs;
+    unsigned int base_stitch, base_prefix;
+    unsigned long long base_words;
+};
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restrict__ ix,
+                                                      const uint8_t* __restrict__ qranks,
+                                                      const uint64_t* __restrict__ qoff, uint64_t nq,
+                                                      QueryDesc d, unsigned long long* __restrict__ ctr)
+{
+    __shared__ BlockCounters bc;
+    if (threadIdx.x == 0) {
+        bc.n_stitch = bc.n_prefix = bc.n_error = bc.n_none = 0;
+        bc.words = bc.pelems = 0;
+        bc.max_runs = 0;
+    }
+    __syncthreads();
+
+    const uint64_t q = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
+    uint64_t src = 0, aux = 0, key = 0;
+    uint32_t cnt = 0, c0 = 0;
+    unsigned int my_stitch = 0, my_prefix = 0;
+    unsigned long long my_words = 0;
+
+    if (q < nq) {
+        const uint64_t b = qoff[q];
+        const uint64_t m = qoff[q + 1] - b;
+        const uint8_t* __restrict__ qr = qranks + b;
+        const uint32_t sigma = ix->sigma;
+        if (m == 0) {
+            status = KMX_Q_EMPTY_QUERY;                       // assert(query.size() > 0), kmer_index.hpp:195
+        } else if (m >= ix->range) {
+            status = KMX_Q_TOO_LONG;                          // :507-509
+        } else {
+            const KmxPlanEntry pe = ix->plan[m];
+            bool ranks_ok = true;
+            if (pe.scheme == KMX_SCHEME_SINGLE) {
+                const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
+                const uint32_t k = el->k;
+                if (m == k) {                                 // :198-205
+                    uint64_t h;
+                    ranks_ok = rank_hash(qr, k, sigma, h);
+                    if (ranks_ok) {
+                        Run r = probe(el, h);
+                        if (r.cnt) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }
+                    }
+                } else if (m < k) {                           // :342-345 -> :115-148
+                    const uint64_t R = ix->pw[k - m];         // fast_pow(sigma, k - size)
+                    if (R > KMX_SUBK_FANOUT_LIMIT) {
+                        status = KMX_Q_SUBK_FANOUT;           // :119-122
+                    } else {
+                        uint64_t hp;
+                        ranks_ok = rank_hash(qr, uint32_t(m), sigma, hp);
+                        if (ranks_ok) {
+                            hp *= R;                          // prefix_hash, :124-129
+                            uint64_t klo, khi;                // key-index range of the prefix
+                            if (el->table_kind == KMX_TABLE_DENSE) {
+                                klo = hp; khi = hp + R;
+                            } else {
+                                klo = lower_bound_dev<uint64_t>(el->ukeys, el->n_ukeys, hp);
+                                khi = lower_bound_dev<uint64_t>(el->ukeys, el->n_ukeys, hp + R);
+                            }
+                            const uint32_t lo = el->offs[klo], hi = el->offs[khi];
+                            // check_last_kmer, :90-112: offsets n-k+i, i in [1, k-m], where no k-mer
+                            // starts but the query still fits.  Bit j of aux <-> position n - j.
+                            const uint8_t* __restrict__ tail = ix->tail + (ix->kmax - k);   // last k letters
+                            uint64_t tmask = 0;
+                            for (uint32_t i = 1; i + m <= k; ++i) {
+                                bool eq = true;
+                                for (uint32_t t = 0; t < m; ++t) eq &= tail[i + t] == qr[t];
+                                if (eq) tmask |= uint64_t(1) << (k - i);
+                            }
+                            const uint32_t len = hi - lo;
+                            cnt = len + uint32_t(__popcll(tmask));
+                            if (cnt) {
+                                kind = KMX_KIND_PREFIX;
+                                src = el->arena_base + lo;
+                                aux = tmask;
+                                key = klo;
+                                c0 = uint32_t(khi - klo);     // number of runs
+                                my_prefix = 1;
+                            }
+                        }
+                    }
+                } else {                                      // m > k, :207-339
+                    const uint32_t P = uint32_t(m / k), rest = uint32_t(m % k);
+                    bool all = true;
+                    Run first{0, 0};
+                    for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
+                        uint64_t h;
+                        ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h);
+                        if (!ranks_ok) break;
+                        Run r = probe(el, h);
+                        if (j == 0) first = r;
+                        all = r.cnt != 0;
+                    }
+                    if (all && ranks_ok) {
+                        if (rest && ix->pw[k - rest] > KMX_SUBK_FANOUT_LIMIT) {
+                            status = KMX_Q_SUBK_FANOUT;       // the rest lookup throws at :119-122 via :234
+                        } else {
+                            if (rest) {
+                                // the rest is verified through the k-mer that ENDS the query
+                                uint64_t h;
+                                ranks_ok = rank_hash(qr + (m - k), k, sigma, h);
+                                all = ranks_ok && probe(el, h).cnt != 0;
+                            }
+                            if (all && ranks_ok) {
+                                kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
+                            }
+                        }
+                    }
+                }
+            } else {                                          // multi-k scheme, :515-557
+                // walk _optimal_nk_sum[m] from its last summand to its first
+                uint64_t mm = m;
+                bool all = true;
+                Run r{0, 0};
+                const uint32_t nparts = pe.nparts;
+                for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
+                    const KmxPlanEntry e = ix->plan[mm];
+                    const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
+                    const uint32_t k = el->k;
+                    mm -= k;                                  // this summand covers [mm, mm + k)
+                    uint64_t h;
+                    ranks_ok = rank_hash(qr + mm, k, sigma, h);
+                    if (!ranks_ok) break;
+                    r = probe(el, h);                         // search_k, :183-190 / :520
+                    all = r.cnt != 0;                         // :521-524
+                }
+                if (all && ranks_ok) {
+                    if (nparts == 1) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }   // :529-530
+                    else { kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt; }
+                }
+            }
+            if (!ranks_ok) { status = KMX_Q_BAD_RANK; kind = KMX_KIND_NONE; cnt = 0; my_prefix = 0; }
+        }
+        if (kind == KMX_KIND_STITCH) {
+            my_stitch = 1;
+            my_words = uint64_t(c0) / 64 + 1;                 // compressed_bitset.hpp:23
+        }
+    }
+
+    // block-aggregated bookkeeping (one global atomic per counter per block, none for
+    // a block of plain exact hits)
+    unsigned int loc_stitch = 0, loc_prefix = 0;
+    unsigned long long loc_words = 0;
+    if (my_stitch) {
+        loc_stitch = atomicAdd(&bc.n_stitch, 1u);
+        loc_words = atomicAdd(&bc.words, my_words);
+    }
+    if (my_prefix) {
+        loc_prefix = atomicAdd(&bc.n_prefix, 1u);
+        atomicAdd(&bc.pelems, (unsigned long long)(cnt - __popcll(aux)));
+        atomicMax(&bc.max_runs, c0);
+    }
+    if (q < nq && status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
+    if (q < nq && status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (bc.n_stitch) {
+            bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
+            bc.base_words = atomicAdd(&ctr[KMX_CTR_MASK_WORDS], bc.words);
+        }
+        if (bc.n_prefix) {
+            bc.base_prefix = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX], (unsigned long long)bc.n_prefix);
+            atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
+            atomicMax(&ctr[KMX_CTR_MAX_RUNS], (unsigned long long)bc.max_runs);
+        }
+        if (bc.n_error) atomicAdd(&ctr[KMX_CTR_ERROR], (unsigned long long)bc.n_error);
+        if (bc.n_none) atomicAdd(&ctr[KMX_CTR_NONE], (unsigned long long)bc.n_none);
+    }
+    __syncthreads();
+
+    if (q < nq) {
+        d.src[q] = src;
+        d.cnt[q] = cnt;
+        d.kind[q] = kind;
+        d.status[q] = status;
+        if (kind == KMX_KIND_STITCH) {
+            d.c0[q] = c0;
+            d.aux[q] = bc.base_words + loc_words;             // first mask word of this query
+            d.stitch_list[bc.base_stitch + loc_stitch] = uint32_t(q);
+        } else if (kind == KMX_KIND_PREFIX) {
+            d.c0[q] = c0;
+            d.aux[q] = aux;
+            d.key[q] = key;
+            d.prefix_list[bc.base_prefix + loc_prefix] = uint32_t(q);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_validate — one wave per STITCH query.
+//
+// Candidates are the positions of the first part's bucket (kmer_index.hpp:272,
+// :532).  Candidate p survives when, for every further part j that starts at
+// query offset s_j, p + s_j is a member of part j's bucket (:279-291, :541-551).
+// A rest that is shorter than k (:230-256) is checked through the k-mer that ends
+// the query (offset m - k) instead of through the sigma^(k-rest) prefix buckets:
+// both decide "the text continues with the rest of the query at p + P*k".
+// 64 candidates = one compressed_bitset word, produced by one ballot.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
+                                                        const uint8_t* __restrict__ qranks,
+                                                        const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                        uint64_t n_stitch, uint64_t* __restrict__ mask_words)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    const uint32_t* __restrict__ arena = ix->arena;
+    const uint32_t sigma = ix->sigma;
+
+    for (uint64_t i = wave; i < n_stitch; i += n_waves) {
+        const uint32_t q = d.stitch_list[i];
+        const uint64_t b = qoff[q];
+        const uint64_t m = qoff[q + 1] - b;
+        const uint8_t* __restrict__ qr = qranks + b;
+        const uint32_t c0 = d.c0[q];
+        const uint64_t src = d.src[q];
+        uint64_t* __restrict__ words = mask_words + d.aux[q];
+        const uint32_t n_words = c0 / 64 + 1;                          // compressed_bitset.hpp:23
+        const KmxPlanEntry pe = ix->plan[m];
+
+        // parts beyond the first one
+        uint32_t n_extra, sk = 0, sP = 0;
+        const KmxElemDev* __restrict__ sel = nullptr;
+        if (pe.scheme == KMX_SCHEME_SINGLE) {
+            sel = &ix->elems[pe.elem];
+            sk = sel->k;
+            sP = uint32_t(m / sk);
+            n_extra = sP - 1 + ((m % sk) ? 1 : 0);
+        } else {
+            n_extra = pe.nparts - 1u;
+        }
+
+        // lane = part: (bucket, offset of the part inside the query)
+        uint64_t p_src = 0;
+        uint32_t p_cnt = 0, p_delta = 0;
+        uint64_t mm = m;   // multi scheme: cursor of the walk over _optimal_nk_sum[m], last summand first
+        auto load_parts = [&](uint32_t base_part, uint32_t chunk) {
+            if (pe.scheme == KMX_SCHEME_SINGLE) {
+                if (lane < chunk) {
+                    const uint32_t part = base_part + lane;
+                    // j = 1 .. P-1 at j*k (:279-291), then, for a rest, the k-mer that ends the query
+                    const uint64_t start = (part < sP - 1) ? uint64_t(part + 1) * sk : (m - sk);
+                    uint64_t h;
+                    rank_hash(qr + start, sk, sigma, h);
+                    const Run r = probe(sel, h);
+                    p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(start);
+                }
+            } else {
+                // the walk is serial and wave-uniform; lane s keeps step s
+                for (uint32_t s = 0; s < chunk; ++s) {
+                    const KmxPlanEntry e = ix->plan[mm];
+                    const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
+                    const uint32_t k = el->k;
+                    mm -= k;                                           // this summand covers [mm, mm + k)
+                    if (lane == s) {
+                        uint64_t h;
+                        rank_hash(qr + mm, k, sigma, h);
+                        const Run r = probe(el, h);                    // search_k, :520
+                        p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(mm);
+                    }
+                }
+            }
+        };
+        auto check_parts = [&](uint32_t chunk, uint32_t p, bool ok) -> bool {
+            for (uint32_t s = 0; s < chunk; ++s) {
+                const uint64_t bs = __shfl(p_src, int(s));
+                const uint32_t bn = __shfl(p_cnt, int(s));
+                const uint32_t dl = __shfl(p_delta, int(s));
+                if (ok) {
+                    const uint32_t x = p + dl;
+                    const uint64_t pos = lower_bound_dev<uint32_t>(arena + bs, bn, x);
+                    ok = pos < bn && arena[bs + pos] == x;             // binary_search :283, lower_bound :544-546
+                }
+                if (!__any(ok)) break;
+            }
+            return ok;
+        };
+
+        const bool one_chunk = n_extra <= KMX_WAVE;
+        if (one_chunk) load_parts(0, n_extra);
+        uint32_t valid = 0;
+        for (uint32_t w = 0; w < n_words; ++w) {
+            const uint32_t ci = w * 64 + lane;
+            bool ok = ci < c0;
+            const uint32_t p = ok ? arena[src + ci] : 0;
+            if (one_chunk) {
+                ok = check_parts(n_extra, p, ok);
+            } else {
+                mm = m;
+                for (uint32_t base_part = 0; base_part < n_extra && __any(ok); base_part += KMX_WAVE) {
+                    const uint32_t chunk = min(uint32_t(KMX_WAVE), n_extra - base_part);
+                    load_parts(base_part, chunk);
+                    ok = check_parts(chunk, p, ok);
+                }
+            }
+            const uint64_t word = __ballot(ok);                        // 64 candidates = one bitset word
+            if (lane == 0) words[w] = word;
+            valid += uint32_t(__popcll(word));
+        }
+        if (lane == 0) d.cnt[q] = valid;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// exclusive scan u32 -> u64 (reduce, spine, downsweep)
+// ---------------------------------------------------------------------------
+#define KMX_SCAN_ITEMS 16
+#define KMX_SCAN_TILE (KMX_BLOCK * KMX_SCAN_ITEMS)
+
+__device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t* total_out)
+{
+    __shared__ uint64_t wave_sum[KMX_BLOCK / KMX_WAVE];
+    const uint32_t lane = lane_id(), w = threadIdx.x / KMX_WAVE;
+    uint64_t inc = v;
+    for (int off = 1; off < KMX_WAVE; off <<= 1) {
+        uint64_t t = __shfl_up(inc, off);
+        if (lane >= uint32_t(off)) inc += t;
+    }
+    if (lane == KMX_WAVE - 1) wave_sum[w] = inc;
+    __syncthreads();
+    uint64_t carry = 0, total = 0;
+    for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i) {
+        uint64_t s = wave_sum[i];
+        if (i < w) carry += s;
+        total += s;
+    }
+    __syncthreads();
+    if (total_out) *total_out = total;
+    return carry + inc - v;
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_scan_reduce(const uint32_t* __restrict__ in, uint64_t n,
+                                                           uint64_t* __restrict__ bsum)
+{
+    const uint64_t base = uint64_t(blockIdx.x) * KMX_SCAN_TILE;
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < KMX_SCAN_ITEMS; ++j) {
+        uint64_t i = base + uint64_t(j) * KMX_BLOCK + threadIdx.x;
+        if (i < n) s += in[i];
+    }
+    uint64_t total;
+    block_exclusive_scan_u64(s, &total);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_scan_spine(uint64_t* __restrict__ bsum, uint64_t nb,
+                                                          unsigned long long* __restrict__ total_out)
+{
+    uint64_t running = 0;
+    for (uint64_t base = 0; base < nb; base += KMX_BLOCK) {
+        uint64_t i = base + threadIdx.x;
+        uint64_t v = i < nb ? bsum[i] : 0;
+        uint64_t total;
+        uint64_t ex = block_exclusive_scan_u64(v, &total);
+        if (i < nb) bsum[i] = running + ex;
+        running += total;
+    }
+    if (threadIdx.x == 0) *total_out = running;
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restrict__ in, uint64_t n,
+                                                         const uint64_t* __restrict__ bsum,
+                                                         uint64_t* __restrict__ out)
+{
+    // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS) of the tile
+    const uint64_t base = uint64_t(blockIdx.x) * KMX_SCAN_TILE + uint64_t(threadIdx.x) * KMX_SCAN_ITEMS;
+    uint32_t v[KMX_SCAN_ITEMS];
+    uint64_t s = 0;
+#pragma unroll
+    for (int j = 0; j < KMX_SCAN_ITEMS; ++j) {
+        uint64_t i = base + j;
+        v[j] = i < n ? in[i] : 0;
+        s += v[j];
+    }
+    uint64_t ex = block_exclusive_scan_u64(s, nullptr) + bsum[blockIdx.x];
+#pragma unroll
+    for (int j = 0; j < KMX_SCAN_ITEMS; ++j) {
+        uint64_t i = base + j;
+        if (i < n) out[i] = ex;
+        ex += v[j];
+        if (i + 1 == n) out[n] = ex;
+    }
+    if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
+}
+
+// ---------------------------------------------------------------------------
+// k_partition — for every tile boundary t*tile the query that owns that output
+// slot: the last q with off[q] <= t*tile.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_partition(const uint64_t* __restrict__ off, uint64_t nq,
+                                                         uint64_t tile, uint64_t n_tiles,
+                                                         uint32_t* __restrict__ tile_q)
+{
+    const uint64_t t = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (t > n_tiles) return;
+    const uint64_t x = t * tile;
+    uint64_t ub = upper_bound_dev<uint64_t>(off, nq + 1, x);   // first index with off > x
+    uint64_t qi = ub ? ub - 1 : 0;
+    if (qi > nq - 1) qi = nq - 1;
+    tile_q[t] = uint32_t(qi);
+}
+
+// ---------------------------------------------------------------------------
+// k_fill — materialises to_vector() (kmer_index_result.hpp:244-260) for EXACT
+// and PREFIX queries, output-centric: one thread block owns KMX_FILL_TILE
+// consecutive output slots whatever the bucket sizes are.
+//   1. every non-empty query that starts inside the tile (plus the one that
+//      covers its first slot) marks its first slot f in LDS and leaves
+//      rec[f] = arena index of the element that belongs in slot f;
+//   2. a max-scan of the marks tells every slot s which first slot f owns it;
+//   3. slot s then copies arena[rec[f] + (s - f)] -> out[tile_base + s]: reads follow
+//      the bucket runs (contiguous inside a run), writes are fully coalesced.
+// ---------------------------------------------------------------------------
+#define REC_SLOW (uint64_t(1) << 63)
+
+template <int E>
+__global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restrict__ ix,
+                                                    const uint64_t* __restrict__ hit_off,
+                                                    const uint32_t* __restrict__ tile_q, uint64_t total,
+                                                    QueryDesc d, uint32_t* __restrict__ out)
+{
+    constexpr int TILE = KMX_BLOCK * E;
+    __shared__ __attribute__((aligned(16))) uint32_t mark[TILE];
+    __shared__ uint64_t rec[TILE];
+    __shared__ uint32_t wave_tot[KMX_BLOCK / KMX_WAVE];
+
+    const uint32_t tid = threadIdx.x;
+    const uint64_t base = uint64_t(blockIdx.x) * TILE;
+    const uint64_t tile_end = min(base + uint64_t(TILE), total);
+    const uint32_t qa = tile_q[blockIdx.x], qb = tile_q[blockIdx.x + 1];
+    const uint32_t* __restrict__ arena = ix->arena;
+
+    // 1. clear marks (blocked, 16-byte LDS stores)
+    {
+        uint4* m4 = reinterpret_cast<uint4*>(mark) + tid * (E / 4);
+#pragma unroll
+        for (int j = 0; j < E / 4; ++j) m4[j] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (uint64_t q = uint64_t(qa) + tid; q <= qb; q += KMX_BLOCK) {
+        const uint64_t s = hit_off[q], e = hit_off[q + 1];
+        if (e > s && e > base && s < tile_end) {
+            const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
+            const uint8_t kind = d.kind[q];
+            mark[slot] = slot + 1;
+            // EXACT: rec = arena index of the element that lands in `slot` (never negative, so
+            // bit 63 stays free for the REC_SLOW flag); slot' >= slot then reads rec + (slot' - slot)
+            rec[slot] = (kind == KMX_KIND_EXACT) ? (d.src[q] + (base + slot - s)) : (REC_SLOW | q);
+        }
+    }
+    __syncthreads();
+
+    // 2. max-scan of the marks in blocked arrangement
+    {
+        uint32_t v[E];
+        uint4* m4 = reinterpret_cast<uint4*>(mark) + tid * (E / 4);
+#pragma unroll
+        for (int j = 0; j < E / 4; ++j) {
+            uint4 t = m4[j];
+            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        }
+        uint32_t last = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) last = v[j] ? v[j] : last;
+        // marks ascend with the slot, so "max of everything before me" = the nearest
+        // earlier lane that has a mark
+        const uint32_t lane = lane_id(), w = tid / KMX_WAVE;
+        const uint64_t has = __ballot(last != 0);
+        const uint64_t below = has & ((uint64_t(1) << lane) - 1);
+        const int srcl = below ? 63 - __clzll(below) : 0;
+        uint32_t carry = __shfl(last, srcl);
+        if (!below) carry = 0;
+        if (lane == KMX_WAVE - 1) wave_tot[w] = last ? last : carry;
+        __syncthreads();
+        uint32_t wcarry = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i)
+            if (i < w) wcarry = max(wcarry, wave_tot[i]);
+        uint32_t run = max(carry, wcarry);
+#pragma unroll
+        for (int j = 0; j < E; ++j) { run = v[j] ? v[j] : run; v[j] = run; }
+#pragma unroll
+        for (int j = 0; j < E / 4; ++j) m4[j] = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+    }
+    __syncthreads();
+
+    // 3. gather: strided arrangement, all loads first, then all stores
+    uint32_t val[E];
+    bool live[E];
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t slot = j * KMX_BLOCK + tid;
+        live[j] = base + slot < tile_end;
+        val[j] = 0;
+        if (live[j]) {
+            const uint32_t st = mark[slot] - 1;
+#ifdef KMX_CHECKED
+            if (st >= uint32_t(TILE)) {
+                unsigned long long* dbg = ix->dbg;
+                if (atomicAdd(&dbg[0], 1ull) == 0) { dbg[1] = blockIdx.x; dbg[2] = slot; dbg[3] = st; dbg[4] = qa; dbg[5] = qb; dbg[6] = base; dbg[7] = 111; }
+                live[j] = false;
+                continue;
+            }
+#endif
+            const uint64_t r = rec[st];
+            if (!(r & REC_SLOW)) {
+#ifdef KMX_CHECKED
+                if (r + (slot - st) >= ix->arena_elems) {
+                    unsigned long long* dbg = ix->dbg;
+                    if (atomicAdd(&dbg[0], 1ull) == 0) { dbg[1] = blockIdx.x; dbg[2] = slot; dbg[3] = st; dbg[4] = qa; dbg[5] = qb; dbg[6] = r; dbg[7] = 222; }
+                    live[j] = false;
+                    continue;
+                }
+#endif
+                val[j] = arena[r + (slot - st)];
+            } else {
+                const uint64_t q = r & ~REC_SLOW;
+                const uint8_t kind = d.kind[q];
+                if (kind == KMX_KIND_PREFIX) {
+                    // slice of every k-mer with this prefix, then the last-kmer offsets
+                    // (kmer_index.hpp:138-146): bit j of aux <-> position n - j
+                    const uint64_t idx = base + slot - hit_off[q];
+                    const uint64_t tmask = d.aux[q];
+                    const uint32_t len = d.cnt[q] - uint32_t(__popcll(tmask));
+                    if (idx < len) {
+                        val[j] = arena[d.src[q] + idx];
+                    } else {
+                        uint32_t t = uint32_t(idx - len);      // t-th smallest position = t-th highest bit
+                        uint64_t mm = tmask;
+                        int bit = 63 - __clzll(mm);
+                        while (t--) { mm &= ~(uint64_t(1) << bit); bit = 63 - __clzll(mm); }
+                        val[j] = uint32_t(ix->n - uint64_t(bit));
+                    }
+                } else {
+                    live[j] = false;                           // STITCH: written by k_compact
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t slot = j * KMX_BLOCK + tid;
+        if (live[j]) out[base + slot] = val[j];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_compact — STITCH queries: decode the mask words and compact the surviving
+// candidates (is_valid + push_back of kmer_index_result.hpp:250-256) with a
+// popcount prefix per word.  One wave per query; candidates are ascending, so
+// the compacted list already is to_vector()'s sorted output.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_compact(const KmxIndexDev* __restrict__ ix, QueryDesc d,
+                                                       uint64_t n_stitch,
+                                                       const uint64_t* __restrict__ mask_words,
+                                                       const uint64_t* __restrict__ hit_off,
+                                                       uint32_t* __restrict__ out)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    const uint32_t* __restrict__ arena = ix->arena;
+    for (uint64_t i = wave; i < n_stitch; i += n_waves) {
+        const uint32_t q = d.stitch_list[i];
+        if (d.cnt[q] == 0) continue;
+        const uint32_t c0 = d.c0[q];
+        const uint64_t src = d.src[q];
+        const uint64_t* __restrict__ words = mask_words + d.aux[q];
+        uint64_t o = hit_off[q];
+        const uint32_t n_words = c0 / 64 + 1;
+        for (uint32_t w = 0; w < n_words; ++w) {
+            const uint64_t word = words[w];
+            if ((word >> lane) & 1) {
+                const uint32_t rank = uint32_t(__popcll(word & ((uint64_t(1) << lane) - 1)));
+                out[o + rank] = arena[src + uint64_t(w) * 64 + lane];
+            }
+            o += uint64_t(__popcll(word));
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_merge_pass — PREFIX queries: the slice copied by k_fill is the concatenation
+// of the ascending runs of consecutive keys; pass t merges neighbouring groups
+// of 2^t runs by ranking every element in its sibling group (no two runs share a
+// position, so ranks are unique).  ceil(log2(max runs)) passes sort every slice,
+// which is the std::sort of kmer_index_result.hpp:258.
+// Element space = concatenation of the PREFIX slices (poff from a scan over
+// prefix_list); buffers alternate between `out` (addressed by hit_off) and `tmp`
+// (addressed by poff).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t n_prefix,
+                                                          uint32_t* __restrict__ plen)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (i >= n_prefix) return;
+    const uint32_t q = d.prefix_list[i];
+    plen[i] = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_merge_pass(const KmxIndexDev* __restrict__ ix,
+                                                          const uint8_t* __restrict__ qranks,
+                                                          const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                          uint64_t n_prefix, const uint64_t* __restrict__ poff,
+                                                          uint64_t p_total, const uint64_t* __restrict__ hit_off,
+                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ tmp,
+                                                          uint32_t pass, int src_is_out)
+{
+    const uint64_t e = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (e >= p_total) return;
+    const uint64_t i = upper_bound_dev<uint64_t>(poff, n_prefix + 1, e) - 1;
+    const uint32_t q = d.prefix_list[i];
+    const uint64_t idx = e - poff[i];
+    const uint32_t* __restrict__ in = src_is_out ? out + hit_off[q] : tmp + poff[i];
+    uint32_t* __restrict__ ot = src_is_out ? tmp + poff[i] : out + hit_off[q];
+
+    const uint64_t m = qoff[q + 1] - qoff[q];
+    const KmxPlanEntry pe = ix->plan[m];
+    const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
+    const uint32_t* __restrict__ offs = el->offs + d.key[q];   // run r spans [offs[r]-offs[0], offs[r+1]-offs[0])
+    const uint32_t n_runs = d.c0[q];
+    const uint32_t o0 = offs[0];
+
+    const uint32_t x = in[idx];
+    // run that holds idx: last r with offs[r] - o0 <= idx
+    const uint64_t r = upper_bound_dev<uint32_t>(offs, uint64_t(n_runs) + 1, uint32_t(o0 + idx)) - 1;
+    const uint64_t g = r >> pass;
+    const uint64_t sib = g ^ 1;
+    const uint64_t sib_first = sib << pass;
+    if (sib_first >= n_runs) { ot[idx] = x; return; }          // no sibling group: carried over
+    const uint64_t own_first = g << pass;
+    const uint32_t own_lo = offs[own_first] - o0;
+    const uint32_t sib_lo = offs[sib_first] - o0;
+    const uint32_t sib_hi = offs[min(uint64_t(n_runs), sib_first + (uint64_t(1) << pass))] - o0;
+    const uint64_t rank = lower_bound_dev<uint32_t>(in + sib_lo, sib_hi - sib_lo, x);
+    const uint32_t pair_lo = min(own_lo, sib_lo);
+    ot[pair_lo + (idx - own_lo) + rank] = x;
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_copy_back(QueryDesc d, uint64_t n_prefix,
+                                                                const uint64_t* __restrict__ poff,
+                                                                uint64_t p_total,
+                                                                const uint64_t* __restrict__ hit_off,
+                                                                uint32_t* __restrict__ out,
+                                                                const uint32_t* __restrict__ tmp)
+{
+    const uint64_t e = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (e >= p_total) return;
+    const uint64_t i = upper_bound_dev<uint64_t>(poff, n_prefix + 1, e) - 1;
+    const uint32_t q = d.prefix_list[i];
+    out[hit_off[q] + (e - poff[i])] = tmp[e];
+}
+
+// ---------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------
+static inline unsigned int blocks_for(uint64_t n, uint64_t per_block)
+{
+    uint64_t b = (n + per_block - 1) / per_block;
+    return (unsigned int)(b ? b : 1);
+}
+
+void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr)
+{
+    hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
+}
+
+void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words)
+{
+    uint64_t waves = n_stitch;
+    unsigned int blocks = (unsigned int)std::min<uint64_t>((waves + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_validate, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, d, n_stitch, mask_words);
+}
+
+uint64_t scan_blocks(uint64_t n) { return blocks_for(n, KMX_SCAN_TILE); }
+
+void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
+                 unsigned long long* total_out)
+{
+    const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
+    hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out);
+}
+
+uint64_t fill_tile() { return uint64_t(KMX_BLOCK) * KMX_FILL_E; }
+
+void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t n_tiles, uint32_t* tile_q)
+{
+    hipLaunchKernelGGL(k_partition, dim3(blocks_for(n_tiles + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, off, nq,
+                       fill_tile(), n_tiles, tile_q);
+}
+
+void launch_fill(hipStream_t s, const KmxIndexDev* ix, const uint64_t* hit_off, const uint32_t* tile_q,
+                 uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
+{
+    hipLaunchKernelGGL(k_fill<KMX_FILL_E>, dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, hit_off, tile_q, total, d, out);
+}
+
+void launch_compact(hipStream_t s, const KmxIndexDev* ix, const QueryDesc& d, uint64_t n_stitch,
+                    const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out)
+{
+    unsigned int blocks = (unsigned int)std::min<uint64_t>((n_stitch + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_compact, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, d, n_stitch, mask_words, hit_off, out);
+}
+
+void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen)
+{
+    hipLaunchKernelGGL(k_prefix_len, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, plen);
+}
+
+void launch_merge_pass(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+                       const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
+                       const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass, int src_is_out)
+{
+    hipLaunchKernelGGL(k_merge_pass, dim3(blocks_for(p_total, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, d,
+                       n_prefix, poff, p_total, hit_off, out, tmp, pass, src_is_out);
+}
+
+void launch_prefix_copy_back(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff,
+                             uint64_t p_total, const uint64_t* hit_off, uint32_t* out, const uint32_t* tmp)
+{
+    hipLaunchKernelGGL(k_prefix_copy_back, dim3(blocks_for(p_total, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, poff,
+                       p_total, hit_off, out, tmp);
+}
+
+} // namespace kmx

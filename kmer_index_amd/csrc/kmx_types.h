@@ -1,0 +1,78 @@
+// Shared host/device layout of the flattened index image and of the per-batch
+// query descriptors.  Everything on the search path is unsigned integer work:
+// u64 rank-hashes, u32 text positions, u64 mask words.
+#pragma once
+#include <stdint.h>
+#include "../../include/kmx.h"
+
+// One slot of the open-addressing table that replaces
+// robin_hood::unordered_map<size_t, std::vector<position_t>> (kmer_index.hpp:52).
+// cnt == 0 marks an empty slot (every stored key owns >= 1 position).
+struct KmxSlot {
+    uint64_t key;
+    uint32_t off;   // first position of the key's run, relative to the element's arena_base
+    uint32_t cnt;
+};
+
+// One kmer_index_element (kmer_index.hpp:39-347) flattened:
+//   positions of all k-mers, grouped by rank-hash in ascending hash order and
+//   ascending inside a group (the order push_back produces at :160-167), stored
+//   in the shared arena at [arena_base, arena_base + npos);
+//   dense table : offs[h] .. offs[h+1] bound the group of hash h (n_offs = sigma^k + 1);
+//   open table  : ukeys[i] (ascending distinct hashes) with offs[i] .. offs[i+1],
+//                 plus KmxSlot slots[1 << log2cap] for O(1) exact probes.
+struct KmxElemDev {
+    uint32_t k;
+    uint32_t table_kind;   // KMX_TABLE_OPEN | KMX_TABLE_DENSE
+    uint32_t log2cap;      // open: log2 of the slot count
+    uint32_t n_ukeys;      // open: number of distinct keys
+    uint64_t n_keys;       // sigma^k
+    uint64_t arena_base;   // element index into the arena
+    uint64_t npos;         // n - k + 1
+    const uint32_t* offs;  // group boundaries, relative to arena_base
+    const KmxSlot* slots;  // open only
+    const uint64_t* ukeys; // open only
+};
+
+// Planner entry for one query length m — what kmer_index::search consults at
+// kmer_index.hpp:512-518 (_use_multi_search_scheme[m], _optimal_nk_sum[m]).
+//   SINGLE: serve the whole query from element `elem` (:512-513)
+//   MULTI : `elem` is the element of the LAST summand of _optimal_nk_sum[m]; the
+//           summands before it are plan[m - k_last] (the DP builds list(q) =
+//           list(q-k) + [k], :434-435); nparts = number of summands.
+enum { KMX_SCHEME_NONE = 0, KMX_SCHEME_SINGLE = 1, KMX_SCHEME_MULTI = 2 };
+struct KmxPlanEntry {
+    uint8_t scheme;
+    uint8_t elem;
+    uint16_t nparts;
+};
+
+struct KmxIndexDev {
+    uint64_t n;            // text length
+    uint32_t sigma;
+    uint32_t n_ks;
+    uint32_t kmax;
+    uint32_t range;        // query lengths >= range are rejected (kmer_index.hpp:507-509)
+    const uint32_t* arena; // every element's positions, back to back
+    const uint8_t* tail;   // last kmax letters of the text (the _last_kmer of every element, :174)
+    const KmxPlanEntry* plan; // [range]
+    uint64_t arena_elems;  // number of positions in the arena
+    unsigned long long* dbg; // KMX_CHECKED builds: 16 words of violation records
+    uint64_t pw[64];       // sigma^j (fast_pow(sigma, j)), saturated to ~0 on overflow
+    KmxElemDev elems[KMX_MAX_KS];
+};
+
+// Counter block written by the lookup kernel and read back once per batch.
+enum {
+    KMX_CTR_EXACT = 0,
+    KMX_CTR_STITCH = 1,
+    KMX_CTR_PREFIX = 2,
+    KMX_CTR_ERROR = 3,
+    KMX_CTR_MASK_WORDS = 4,   // bump allocator for STITCH mask words
+    KMX_CTR_PREFIX_ELEMS = 5, // sum of PREFIX slice lengths
+    KMX_CTR_MAX_RUNS = 6,     // max number of runs of any PREFIX query
+    KMX_CTR_TOTAL_HITS = 7,   // written by the scan
+    KMX_CTR_NONE = 8,         // valid queries without a hit
+    KMX_CTR_PREFIX_TOTAL = 9, // total of the scan over PREFIX slice lengths
+    KMX_CTR_COUNT = 16
+};

@@ -1,0 +1,255 @@
+"""ctypes binding of the C-ABI (include/kmx.h) — plumbing for tests, bench.py and smoke().
+
+Every search goes through libkmx.so (hand-written gfx950 kernels).  There is no Python or
+CPU search path in this package: when the library or a device is missing, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+KMX_MAX_KS = 32
+KMX_N_KERNELS = 16
+TABLE_AUTO, TABLE_OPEN, TABLE_DENSE = 0, 1, 2
+SEARCH_DEFAULT, SEARCH_KEEP_MASKS, SEARCH_COUNT_ONLY = 0, 1, 2
+KIND_NONE, KIND_EXACT, KIND_STITCH, KIND_PREFIX = 0, 1, 2, 3
+Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
+
+# every symbol include/kmx.h declares
+EXPORTS = [
+    "kmx_index_build", "kmx_index_free", "kmx_index_info", "kmx_index_arena_host", "kmx_plan", "kmx_fast_pow",
+    "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
+    "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
+    "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
+]
+
+
+class KmxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"kmx status {status}: {msg}")
+        self.status = status
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_kind", C.c_uint32),
+                ("n_threads", C.c_uint32), ("query_size_range", C.c_uint32), ("keep_host_arena", C.c_uint32),
+                ("reserved", C.c_uint32 * 2)]
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+_lib = None
+
+
+def lib():
+    """Loads kmer_index_amd/libkmx.so, building it first when stale (hipcc, gfx950)."""
+    global _lib
+    if _lib is None:
+        path = _build.build()
+        if not os.path.exists(path):
+            raise RuntimeError("libkmx.so is missing and could not be built; the engine has no fallback")
+        L = C.CDLL(path)
+        vp, u64, u32 = C.c_void_p, C.c_uint64, C.c_uint32
+        P = C.POINTER
+        L.kmx_index_build.restype = C.c_int
+        L.kmx_index_build.argtypes = [vp, u64, u32, vp, u32, P(Options), P(vp)]
+        L.kmx_index_free.argtypes = [vp]
+        L.kmx_index_info.restype = C.c_int
+        L.kmx_index_info.argtypes = [vp, P(u64), P(u32), P(u32), vp, vp, P(u64)]
+        L.kmx_index_arena_host.restype = C.c_int
+        L.kmx_index_arena_host.argtypes = [vp, P(vp), P(u64)]
+        L.kmx_plan.restype = C.c_int
+        L.kmx_plan.argtypes = [vp, u32, u32, vp, vp, vp, u64, P(u64)]
+        L.kmx_fast_pow.restype = u64
+        L.kmx_fast_pow.argtypes = [u64, C.c_uint8]
+        L.kmx_search_batch.restype = C.c_int
+        L.kmx_search_batch.argtypes = [vp, vp, vp, u64, u32, P(vp)]
+        L.kmx_search_batch_device.restype = C.c_int
+        L.kmx_search_batch_device.argtypes = [vp, vp, vp, u64, u32, vp, P(vp)]
+        L.kmx_result_counts.restype = C.c_int
+        L.kmx_result_counts.argtypes = [vp] + [P(u64)] * 6
+        L.kmx_result_view_device.restype = C.c_int
+        L.kmx_result_view_device.argtypes = [vp, P(vp), P(vp), P(vp)]
+        L.kmx_result_view.restype = C.c_int
+        L.kmx_result_view.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
+        L.kmx_result_masks.restype = C.c_int
+        L.kmx_result_masks.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
+        L.kmx_result_free.argtypes = [vp]
+        L.kmx_stats_enable.restype = C.c_int
+        L.kmx_stats_enable.argtypes = [vp, C.c_int]
+        L.kmx_stats_get.restype = C.c_int
+        L.kmx_stats_get.argtypes = [vp, P(KernelStat), P(u32)]
+        L.kmx_stats_reset.restype = C.c_int
+        L.kmx_stats_reset.argtypes = [vp]
+        L.kmx_debug_words.restype = C.c_int
+        L.kmx_debug_words.argtypes = [vp, vp]
+        L.kmx_last_error.restype = C.c_char_p
+        L.kmx_status_string.restype = C.c_char_p
+        L.kmx_status_string.argtypes = [C.c_int]
+        L.kmx_version.restype = u32
+        _lib = L
+    return _lib
+
+
+def _check(st):
+    if st != 0:
+        raise KmxError(st, lib().kmx_last_error().decode())
+
+
+def fast_pow(base, exp):
+    return int(lib().kmx_fast_pow(base, exp))
+
+
+def plan(ks, rng=10000):
+    """(use_multi[rng] bool, nk_sum list of lists) from kmx_plan (host only, no device needed)."""
+    ks = np.ascontiguousarray(ks, np.uint32)
+    multi = np.zeros(rng, np.uint8)
+    off = np.zeros(rng + 1, np.uint32)
+    n = C.c_uint64()
+    _check(lib().kmx_plan(ks.ctypes.data, ks.size, rng, multi.ctypes.data, off.ctypes.data, None, 0, C.byref(n)))
+    flat = np.zeros(max(n.value, 1), np.uint32)
+    _check(lib().kmx_plan(ks.ctypes.data, ks.size, rng, multi.ctypes.data, off.ctypes.data, flat.ctypes.data, n.value, C.byref(n)))
+    return multi.astype(bool), [flat[off[q]:off[q + 1]].tolist() for q in range(rng)]
+
+
+def _view(ptr, n, dtype):
+    if not ptr or n == 0:
+        return np.zeros(0, dtype)
+    ct = np.ctypeslib.as_ctypes_type(dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ct)), shape=(int(n),))
+
+
+class Result:
+    """Owns a kmx_result handle."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+
+    def counts(self):
+        v = [C.c_uint64() for _ in range(6)]
+        _check(lib().kmx_result_counts(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(["nq", "n_hits", "n_exact", "n_stitch", "n_prefix", "n_error"], [int(x.value) for x in v]))
+
+    def host(self):
+        """(hit_off[nq+1], positions, status[nq], kinds[nq]) as numpy copies."""
+        c = self.counts()
+        a, b, s, k = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().kmx_result_view(self._h, C.byref(a), C.byref(b), C.byref(s), C.byref(k)))
+        nq = c["nq"]
+        hit_off = _view(a.value, nq + 1, np.uint64).copy()
+        n_pos = int(hit_off[nq]) if b.value else 0        # positions are NULL for COUNT_ONLY results
+        return (hit_off, _view(b.value, n_pos, np.uint32).copy(), _view(s.value, nq, np.uint8).copy(),
+                _view(k.value, nq, np.uint8).copy())
+
+    def device_ptrs(self):
+        a, b, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().kmx_result_view_device(self._h, C.byref(a), C.byref(b), C.byref(s)))
+        return a.value, b.value, s.value
+
+    def masks(self):
+        c = self.counts()
+        a, b, cc, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().kmx_result_masks(self._h, C.byref(a), C.byref(b), C.byref(cc), C.byref(d)))
+        nq = c["nq"]
+        base = _view(a.value, nq, np.uint64).copy()
+        cnt = _view(cc.value, nq, np.uint32).copy()
+        src = _view(d.value, nq, np.uint64).copy()
+        return base, b.value, cnt, src
+
+    def close(self):
+        if self._h:
+            lib().kmx_result_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Index:
+    """kmx_index handle: the flattened kmer_index<alphabet_t, uint32_t, ks...> resident in HBM."""
+
+    def __init__(self, ranks, sigma, ks, table=TABLE_AUTO, device=-1, n_threads=0, keep_host_arena=False,
+                 query_size_range=0):
+        ranks = np.ascontiguousarray(ranks, np.uint8)
+        ks = np.ascontiguousarray(ks, np.uint32)
+        self.ks = ks.tolist()
+        self.sigma = int(sigma)
+        self.n = int(ranks.size)
+        o = Options()
+        o.struct_size = C.sizeof(Options)
+        o.device = device
+        o.table_kind = table
+        o.n_threads = n_threads
+        o.query_size_range = query_size_range
+        o.keep_host_arena = int(keep_host_arena)
+        self._h = C.c_void_p()
+        _check(lib().kmx_index_build(ranks.ctypes.data, ranks.size, self.sigma, ks.ctypes.data, ks.size,
+                                     C.byref(o), C.byref(self._h)))
+
+    def info(self):
+        n, sigma, nks, dbytes = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()
+        ks = np.zeros(KMX_MAX_KS, np.uint32)
+        tk = np.zeros(KMX_MAX_KS, np.uint32)
+        _check(lib().kmx_index_info(self._h, C.byref(n), C.byref(sigma), C.byref(nks), ks.ctypes.data, tk.ctypes.data, C.byref(dbytes)))
+        return {"n": n.value, "sigma": sigma.value, "ks": ks[:nks.value].tolist(), "tables": tk[:nks.value].tolist(),
+                "device_bytes": dbytes.value}
+
+    def arena_host(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        _check(lib().kmx_index_arena_host(self._h, C.byref(p), C.byref(n)))
+        return _view(p.value, n.value, np.uint32)
+
+    def search(self, qranks, qoff, flags=SEARCH_DEFAULT, result=None):
+        """Host-buffer batch search (kmx_search_batch)."""
+        qranks = np.ascontiguousarray(qranks, np.uint8)
+        qoff = np.ascontiguousarray(qoff, np.uint64)
+        r = result or Result()
+        _check(lib().kmx_search_batch(self._h, qranks.ctypes.data if qranks.size else None, qoff.ctypes.data,
+                                      qoff.size - 1, flags, C.byref(r._h)))
+        return r
+
+    def search_device(self, d_qranks_ptr, d_qoff_ptr, nq, flags=SEARCH_DEFAULT, stream=0, result=None):
+        """Device-buffer batch search (kmx_search_batch_device) on a caller-owned hipStream_t."""
+        r = result or Result()
+        _check(lib().kmx_search_batch_device(self._h, d_qranks_ptr, d_qoff_ptr, nq, flags, stream or None, C.byref(r._h)))
+        return r
+
+    def debug_words(self):
+        w = np.zeros(16, np.uint64)
+        _check(lib().kmx_debug_words(self._h, w.ctypes.data))
+        return w
+
+    def stats_enable(self, on=True):
+        _check(lib().kmx_stats_enable(self._h, int(on)))
+
+    def stats_reset(self):
+        _check(lib().kmx_stats_reset(self._h))
+
+    def stats(self):
+        arr = (KernelStat * KMX_N_KERNELS)()
+        n = C.c_uint32()
+        _check(lib().kmx_stats_get(self._h, arr, C.byref(n)))
+        return {arr[i].name.decode(): {"launches": int(arr[i].launches), "total_ms": float(arr[i].total_ms)} for i in range(n.value)}
+
+    def close(self):
+        if self._h:
+            lib().kmx_index_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def split_hits(hit_off, positions):
+    """List of per-query position arrays."""
+    return [positions[int(hit_off[i]):int(hit_off[i + 1])] for i in range(len(hit_off) - 1)]

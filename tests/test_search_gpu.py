@@ -1,0 +1,141 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle and the naive scan."""
+import numpy as np
+import pytest
+
+from kmer_index_amd import synth
+from tests.helpers import make_queries, pack
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # (name, sigma, n, ks, lengths)  — lengths stay inside the reference's correct envelope
+    ("dna4_k5", 4, 100_000, [5], list(range(1, 16)) + [20]),
+    ("dna4_k10", 4, 400_000, [10], list(range(4, 31)) + [40]),
+    ("dna5_k10", 5, 400_000, [10], list(range(5, 31))),
+    ("aa20_k5", 20, 300_000, [5], list(range(1, 16))),
+    ("dna4_multi", 4, 400_000, [8, 10, 12], list(range(2, 30)) + [33, 35]),
+    ("dna15_k3_multi", 15, 200_000, [3, 4, 5], list(range(1, 10))),
+]
+
+
+def _compare(engine, orc, text, sigma, ks, qranks, qoff, table):
+    idx = engine.Index(text, sigma, ks, table=table)
+    res = idx.search(qranks, qoff)
+    hit_off, positions, status, kinds = res.host()
+    oidx = orc.Index(text, sigma, ks)
+    o_off, o_pos, o_status, _ = oidx.search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=4)
+    n_off, n_pos = orc.naive_batch(text, qranks, qoff)
+    ok_mask = o_status == 0
+    assert np.array_equal(status, o_status.astype(np.uint8)), "per-query status differs from the oracle"
+    assert np.array_equal(hit_off, o_off), "hit_off differs from the oracle"
+    assert np.array_equal(positions, o_pos), "positions differ from the oracle"
+    # ground truth for every query the reference does not reject
+    for i in np.nonzero(ok_mask)[0]:
+        a = positions[int(hit_off[i]):int(hit_off[i + 1])]
+        b = n_pos[int(n_off[i]):int(n_off[i + 1])]
+        assert np.array_equal(a, b), f"query {i} (m={int(qoff[i+1]-qoff[i])}) differs from the naive scan"
+    res.close()
+    idx.close()
+    return kinds
+
+
+@pytest.mark.parametrize("table", ["open", "dense"])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_parity_vs_oracle_and_naive(engine, orc, case, table):
+    name, sigma, n, ks, lengths = case
+    text = synth.ranks(1000 + len(name), n, sigma)
+    qranks, qoff = make_queries(text, sigma, lengths, 30, seed=77)
+    tk = engine.TABLE_OPEN if table == "open" else engine.TABLE_DENSE
+    kinds = _compare(engine, orc, text, sigma, ks, qranks, qoff, tk)
+    assert (kinds == engine.KIND_EXACT).any()
+
+
+def test_exact_k10_large_batch(engine, orc):
+    """The headline shape, down-scaled: uniform random 10-mers, every one present many times."""
+    text = synth.ranks(1002, 2_000_000, 4)
+    qranks, qoff = synth.uniform_queries(2002, 200_000, 10, 4)
+    idx = engine.Index(text, 4, [10], table=engine.TABLE_OPEN)
+    res = idx.search(qranks, qoff)
+    hit_off, positions, status, kinds = res.host()
+    oidx = orc.Index(text, 4, [10])
+    o_off, o_pos, o_status, _ = oidx.search_batch(qranks, qoff, n_threads=8)
+    assert np.array_equal(hit_off, o_off)
+    assert np.array_equal(positions, o_pos)
+    assert (status == 0).all()
+    c = res.counts()
+    assert c["n_exact"] + (kinds == engine.KIND_NONE).sum() == 200_000
+    # size-independent properties: every list ascending, every hit re-hashes to its query
+    d = np.diff(positions.astype(np.int64))
+    starts = hit_off[1:-1].astype(np.int64)
+    inner = np.ones(positions.size - 1, bool)
+    inner[starts[(starts > 0) & (starts < positions.size)] - 1] = False
+    assert (d[inner] > 0).all()
+    qi = np.repeat(np.arange(200_000), np.diff(hit_off).astype(np.int64))
+    for j in range(10):
+        assert np.array_equal(text[positions.astype(np.int64) + j], qranks.reshape(-1, 10)[qi, j])
+
+
+def test_edge_cases(engine, orc):
+    text = synth.ranks(5, 5000, 4)
+    idx = engine.Index(text, 4, [6, 9])
+    # empty batch
+    r = idx.search(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    ho, pos, st, kd = r.host()
+    assert ho.tolist() == [0] and pos.size == 0
+    # empty query, too-long query, bad rank, and a normal one in the same batch
+    qs = [np.zeros(0, np.uint8), np.zeros(10000, np.uint8), np.array([0, 1, 7, 2, 1, 0], np.uint8), text[10:16].copy(),
+          text[4994:5000].copy(), text[0:9].copy(), np.zeros(9999, np.uint8)]
+    qranks, qoff = pack(qs)
+    r = idx.search(qranks, qoff)
+    ho, pos, st, kd = r.host()
+    assert st.tolist()[:5] == [engine.Q_EMPTY_QUERY, engine.Q_TOO_LONG, engine.Q_BAD_RANK, engine.Q_OK, engine.Q_OK]
+    hits = engine.split_hits(ho, pos)
+    assert 10 in hits[3].tolist() and 4994 in hits[4].tolist() and 0 in hits[5].tolist()
+    for i in (3, 4, 5, 6):
+        assert np.array_equal(hits[i], orc.naive_scan(text, qs[i]))
+
+
+def test_subk_fanout_error_matches_reference(engine, orc):
+    """sigma^(k-m) > 1e7 throws in the reference (kmer_index.hpp:119-122), also via the rest of a long query."""
+    text = synth.ranks(9, 300_000, 4)
+    idx = engine.Index(text, 4, [13])
+    oidx = orc.Index(text, 4, [13])
+    qs = [text[100:101].copy(), text[100:102].copy(), text[100:113 + 1].copy(), text[100:113 + 2].copy(),
+          synth.ranks(1, 14, 4), text[5:5 + 12].copy()]
+    qranks, qoff = pack(qs)
+    r = idx.search(qranks, qoff)
+    ho, pos, st, kd = r.host()
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff)
+    assert np.array_equal(st, o_st.astype(np.uint8))
+    assert engine.Q_SUBK_FANOUT in st.tolist()
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+
+
+def test_masks_match_oracle_bitset(engine, orc):
+    """KEEP_MASKS: candidate run + compressed_bitset words equal the reference-shaped result object."""
+    text = synth.ranks(21, 200_000, 4)
+    ks = [8, 10, 12]
+    idx = engine.Index(text, 4, ks, keep_host_arena=True)
+    oidx = orc.Index(text, 4, ks)
+    qranks, qoff = make_queries(text, 4, [13, 16, 19, 20, 22, 24, 27], 12, seed=5)
+    r = idx.search(qranks, qoff, flags=engine.SEARCH_KEEP_MASKS)
+    ho, pos, st, kd = r.host()
+    base, words_ptr, cand_cnt, cand_src = r.masks()
+    arena = idx.arena_host()
+    import ctypes as C
+    n_checked = 0
+    for i in range(qoff.size - 1):
+        if kd[i] != engine.KIND_STITCH:
+            continue
+        q = qranks[int(qoff[i]):int(qoff[i + 1])]
+        ost, opos, om = oidx.search(q, want_mask=True)
+        assert not om["bypass"] and om["candidates"] == cand_cnt[i]
+        nw = cand_cnt[i] // 64 + 1
+        words = np.ctypeslib.as_array(C.cast(words_ptr, C.POINTER(C.c_uint64)), shape=(int(base[i]) + nw,))[int(base[i]):]
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:cand_cnt[i]].astype(bool)
+        obits = np.unpackbits(om["words"].view(np.uint8), bitorder="little")[:om["bits"]].astype(bool)
+        assert np.array_equal(bits, obits)
+        cands = arena[int(cand_src[i]):int(cand_src[i]) + int(cand_cnt[i])]
+        assert np.array_equal(cands[bits], pos[int(ho[i]):int(ho[i + 1])])
+        n_checked += 1
+    assert n_checked > 10
