@@ -1,0 +1,100 @@
+"""CPU suite, part 2: the product library without a GPU — it loads, exports every symbol of include/kmx.h,
+its host-only entry points (planner, fast_pow) equal the oracle, and search refuses to run without a device."""
+import json
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "kmx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmx_[a-z_0-9]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(engine):
+    declared = _declared_symbols()
+    assert len(declared) >= 19
+    L = engine.lib()
+    missing = [s for s in declared if not hasattr(L, s)]
+    assert not missing, missing
+    assert sorted(engine.EXPORTS) == declared
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "kmer_index_amd", "libkmx.so")], capture_output=True, text=True).stdout
+    for s in declared:
+        assert f" T {s}" in out
+
+
+def test_library_carries_gfx950_code_objects():
+    """The .so embeds a gfx950 code object holding every kernel (no other arch, no fallback)."""
+    lib = os.path.join(ROOT, "kmer_index_amd", "libkmx.so")
+    data = open(lib, "rb").read()
+    assert b"amdgcn-amd-amdhsa--gfx950" in data
+    for arch in (b"gfx90a", b"gfx942", b"sm_"):
+        assert b"amdgcn-amd-amdhsa--" + arch not in data
+    for kern in (b"k_lookup", b"k_fill", b"k_validate", b"k_compact", b"k_merge_pass", b"k_scan_down", b"k_partition"):
+        assert kern in data
+
+
+def test_fast_pow_matches_oracle_and_golden(engine, orc):
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "fast_pow.json")))["rows"]
+    for b, e, want in rows:
+        assert engine.fast_pow(b, e) == want == orc.fast_pow(b, e)
+
+
+@pytest.mark.parametrize("ks", [[5], [10], [8, 10, 12], [9, 11, 13, 17], [3, 4, 5], [31], [12, 8, 10], [1], [2, 9]])
+def test_planner_matches_oracle(engine, orc, ks):
+    m1, n1 = engine.plan(ks)
+    m2, n2 = orc.plan(ks)
+    assert np.array_equal(m1, m2)
+    assert n1 == n2
+
+
+def test_planner_thesis_kat(engine):
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "planner.json")))["thesis"]
+    multi, nk = engine.plan(gold["ks"])
+    assert nk[29] == [9, 9, 11] and nk[30] == [13, 17] and nk[31] == [9, 9, 13] and nk[33] == [9, 11, 13]
+    assert not multi[32] and len(nk[32]) == 1
+
+
+def test_argument_validation_without_device(engine):
+    import ctypes as C
+    L = engine.lib()
+    out = C.c_void_p()
+    ranks = np.zeros(100, np.uint8)
+    ks = np.array([5], np.uint32)
+    # k >= 64 / log2(sigma) is the reference's static_assert (kmer_index.hpp:42-43)
+    bad = np.array([32], np.uint32)
+    st = L.kmx_index_build(ranks.ctypes.data, 100, 4, bad.ctypes.data, 1, None, C.byref(out))
+    assert st == 1 and b"valid k" in L.kmx_last_error()
+    st = L.kmx_index_build(ranks.ctypes.data, 3, 4, ks.ctypes.data, 1, None, C.byref(out))
+    assert st == 1
+    st = L.kmx_index_build(None, 100, 4, ks.ctypes.data, 1, None, C.byref(out))
+    assert st == 1
+
+
+def test_no_cpu_fallback(engine):
+    """Without a device the product path fails loudly instead of computing on the host."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible here")
+    with pytest.raises(engine.KmxError) as e:
+        engine.Index(np.zeros(1000, np.uint8), 4, [5])
+    assert e.value.status == 4      # KMX_ERR_NO_DEVICE
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under kmer_index_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("kmer_index_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                    if re.search(r"\boracle\b|liboracle|orc_", txt):
+                        bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
