@@ -33,7 +33,8 @@ def main():
     ap.add_argument("--nq", type=int, default=10_000_000, help="queries per GPU per step")
     ap.add_argument("--table", choices=["open", "dense", "auto"], default="open")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample", type=int, default=2_000_000, help="queries in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
     ap.add_argument("--verify", type=int, default=20000, help="queries checked against the oracle after timing")
     args = ap.parse_args()
 
@@ -123,7 +124,8 @@ def main():
         hit_off, positions, status, kinds = res.host()
         if world == 1 and not args.no_cpu_baseline:
             t1 = time.time()
-            T = os.cpu_count() or 1
+            usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            T = args.cpu_threads or max(1, min(16, usable))
             oidx = orc.Index(text, args.sigma, [args.k], n_threads=T)
             log(f"oracle (CPU restatement) index built in {time.time() - t1:.1f}s")
             ns = min(args.cpu_sample, nq)

@@ -129,7 +129,10 @@ struct kmx_index {
     std::vector<void*> allocs;          // device allocations owned by the index
     uint64_t device_bytes = 0;
     KmxIndexDev* d_index = nullptr;     // device copy of the header
+    const uint32_t* d_arena = nullptr;  // the position arena (also in the header; passed to kernels directly)
     unsigned long long* d_dbg = nullptr; // KMX_CHECKED violation records
+    kmx::FillVariant fill_variant{8, false, true};   // 2048-slot tiles, dword gathers, non-temporal stores
+    bool rec32 = true;                   // every arena index fits 31 bits
     std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
     hipStream_t stream = nullptr;       // internal stream of the host-buffer search form
     std::mutex host_call_mu;
@@ -321,13 +324,20 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     for (auto& im : images) arena_elems += im.npos;
     {
         void* p = nullptr;
-        hipError_t e = hipMalloc(&p, std::max<uint64_t>(arena_elems * 4, 16));
+        hipError_t e = hipMalloc(&p, arena_elems * 4 + 64);   // padded: k_fill reads 16 bytes at any element
         if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
         ix->allocs.push_back(p);
         ix->device_bytes += arena_elems * 4;
         h.arena = static_cast<const uint32_t*>(p);
+        ix->d_arena = h.arena;
     }
     h.arena_elems = arena_elems;
+    ix->rec32 = arena_elems < (uint64_t(1) << 31);
+    if (const char* fvs = getenv("KMX_FILL_VARIANT")) {
+        // tuning knob: "<e>[v][n]", e.g. "8v", "16vn", "8"
+        int e = atoi(fvs);
+        if (e == 4 || e == 8 || e == 12 || e == 16) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'v') != nullptr, strchr(fvs, 'n') != nullptr};
+    }
     {
         void* p = nullptr;
         if (hipMalloc(&p, 16 * 8) == hipSuccess) { (void)hipMemset(p, 0, 16 * 8); ix->allocs.push_back(p); h.dbg = static_cast<unsigned long long*>(p); ix->d_dbg = h.dbg; }
@@ -504,7 +514,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
 
     if (r->n_stitch) {
         HIP_TRY(r->mask_words.ensure(r->n_mask_words * 8));
-        timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, qr, qo, d, r->n_stitch, r->mask_words.as<uint64_t>()); });
+        timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, r->n_stitch, r->mask_words.as<uint64_t>()); });
         timed(ix, K_SCAN, s, [&] {
             kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
         });
@@ -516,17 +526,18 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
 
     const uint64_t total = r->n_hits;
     if (total == 0) return KMX_OK;
-    const uint64_t tile = kmx::fill_tile();
+    const kmx::FillVariant fv = ix->fill_variant;
+    const uint64_t tile = kmx::fill_tile(fv);
     const uint64_t n_tiles = (total + tile - 1) / tile;
     if (n_tiles >= 0x7FFFFFFFull) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: result too large, split the batch");
     HIP_TRY(r->out.ensure(total * 4));
     HIP_TRY(r->tile_q.ensure((n_tiles + 1) * 4));
     uint32_t* out = r->out.as<uint32_t>();
     const uint64_t* hit_off = r->hit_off.as<uint64_t>();
-    timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, n_tiles, r->tile_q.as<uint32_t>()); });
-    timed(ix, K_FILL, s, [&] { kmx::launch_fill(s, dix, hit_off, r->tile_q.as<uint32_t>(), total, n_tiles, d, out); });
+    timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, tile, n_tiles, r->tile_q.as<uint32_t>()); });
+    timed(ix, K_FILL, s, [&] { kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, hit_off, r->tile_q.as<uint32_t>(), total, n_tiles, d, out); });
     if (r->n_stitch)
-        timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, dix, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
+        timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
 
     if (r->n_prefix && max_runs > 1 && prefix_elems > 0) {
         // merge the per-key runs of every PREFIX slice into one ascending list
@@ -647,6 +658,7 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
             HIP_TRY(hipMemcpy(r->h_mask_base.p, r->aux.p, r->nq * 8, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(r->h_cand_count.p, r->c0.p, r->nq * 4, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(r->h_cand_src.p, r->src.p, r->nq * 8, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < r->nq; ++i) r->h_cand_src.as<uint64_t>()[i] &= ~(uint64_t(1) << 63);   // internal flag
         }
         if (r->n_mask_words) HIP_TRY(hipMemcpy(r->h_mask_words.p, r->mask_words.p, r->n_mask_words * 8, hipMemcpyDeviceToHost));
         r->host_masks_valid = true;

@@ -4,9 +4,6 @@
 #include <stdint.h>
 #include "kmx_types.h"
 
-#ifndef KMX_FILL_E
-#define KMX_FILL_E 8   // output slots per thread in k_fill (tile = 256 * KMX_FILL_E slots)
-#endif
 
 namespace kmx {
 
@@ -25,16 +22,23 @@ struct QueryDesc {
 
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr);
-void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);
 void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
                  unsigned long long* total_out);
-uint64_t fill_tile();
-void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t n_tiles, uint32_t* tile_q);
-void launch_fill(hipStream_t s, const KmxIndexDev* ix, const uint64_t* hit_off, const uint32_t* tile_q,
-                 uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out);
-void launch_compact(hipStream_t s, const KmxIndexDev* ix, const QueryDesc& d, uint64_t n_stitch,
+// k_fill build variants: e = output slots per thread (tile = 256 * e), vec = 16-byte quads,
+// nt = non-temporal stores of the hit lists.
+struct FillVariant {
+    int e;
+    bool vec;
+    bool nt;
+};
+uint64_t fill_tile(const FillVariant& v);
+void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q);
+void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
+                 const uint32_t* tile_q, uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out);
+void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,
                     const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out);
 void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen);
 void launch_merge_pass(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,

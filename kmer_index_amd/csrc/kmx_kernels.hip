@@ -27,10 +27,36 @@
 
 namespace kmx {
 
+// Flag in QueryDesc::src: the query is not a plain bucket copy (STITCH / PREFIX): k_fill
+// serves PREFIX slot by slot and leaves STITCH to k_compact.
+#define SRC_SLOW (uint64_t(1) << 63)
+
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (KMX_WAVE - 1); }
+
+// Pointers that are loaded from the index header are "generic" to the compiler, which then
+// emits flat_load (counted on BOTH vmcnt and lgkmcnt, so every LDS wait would also drain the
+// outstanding global loads).  Everything the header points to lives in HBM: say so.
+#define KMX_GLOBAL __attribute__((address_space(1)))
+template <typename T>
+__device__ __forceinline__ const KMX_GLOBAL T* as_global(const T* p)
+{
+    return (const KMX_GLOBAL T*)p;
+}
+typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+
+// plan[m] as one 32-bit load ({u8 scheme, u8 elem, u16 nparts}, little endian)
+__device__ __forceinline__ KmxPlanEntry load_plan(const KmxIndexDev* __restrict__ ix, uint64_t m)
+{
+    const uint32_t raw = ((const KMX_GLOBAL uint32_t*)ix->plan)[m];
+    KmxPlanEntry e;
+    e.scheme = uint8_t(raw & 0xFF);
+    e.elem = uint8_t((raw >> 8) & 0xFF);
+    e.nparts = uint16_t(raw >> 16);
+    return e;
+}
 
 struct Run {
     uint64_t src;   // arena index of the run's first position
@@ -47,18 +73,18 @@ __device__ __forceinline__ Run probe(const KmxElemDev* __restrict__ el, uint64_t
 {
     Run r;
     if (el->table_kind == KMX_TABLE_DENSE) {
-        const uint32_t* __restrict__ offs = el->offs;
+        const KMX_GLOBAL uint32_t* offs = as_global(el->offs);
         uint32_t a = offs[h], b = offs[h + 1];
         r.src = el->arena_base + a;
         r.cnt = b - a;
         return r;
     }
-    const KmxSlot* __restrict__ slots = el->slots;
+    const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);
     const uint64_t mask = (uint64_t(1) << el->log2cap) - 1;
     uint64_t s = slot_hash_dev(h, el->log2cap);
     for (;;) {
         // one 16-byte slot: {key, off, cnt}
-        const ulonglong2 raw = *reinterpret_cast<const ulonglong2*>(slots + s);
+        const u64x2 raw = *(const KMX_GLOBAL u64x2*)(slots + s);
         uint32_t off = uint32_t(raw.y), cnt = uint32_t(raw.y >> 32);
         if (cnt == 0) { r.src = 0; r.cnt = 0; return r; }
         if (raw.x == h) { r.src = el->arena_base + off; r.cnt = cnt; return r; }
@@ -67,8 +93,8 @@ __device__ __forceinline__ Run probe(const KmxElemDev* __restrict__ el, uint64_t
 }
 
 // first index i in [0, n) with a[i] >= x (n if none)
-template <typename T>
-__device__ __forceinline__ uint64_t lower_bound_dev(const T* __restrict__ a, uint64_t n, T x)
+template <typename T, typename P>
+__device__ __forceinline__ uint64_t lower_bound_dev(P a, uint64_t n, T x)
 {
     uint64_t lo = 0, hi = n;
     while (lo < hi) {
@@ -78,8 +104,8 @@ __device__ __forceinline__ uint64_t lower_bound_dev(const T* __restrict__ a, uin
     return lo;
 }
 // first index i in [0, n) with a[i] > x (n if none)
-template <typename T>
-__device__ __forceinline__ uint64_t upper_bound_dev(const T* __restrict__ a, uint64_t n, T x)
+template <typename T, typename P>
+__device__ __forceinline__ uint64_t upper_bound_dev(P a, uint64_t n, T x)
 {
     uint64_t lo = 0, hi = n;
     while (lo < hi) {
@@ -146,7 +172,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         } else if (m >= ix->range) {
             status = KMX_Q_TOO_LONG;                          // :507-509
         } else {
-            const KmxPlanEntry pe = ix->plan[m];
+            const KmxPlanEntry pe = load_plan(ix, m);
             bool ranks_ok = true;
             if (pe.scheme == KMX_SCHEME_SINGLE) {
                 const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
@@ -171,13 +197,13 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                             if (el->table_kind == KMX_TABLE_DENSE) {
                                 klo = hp; khi = hp + R;
                             } else {
-                                klo = lower_bound_dev<uint64_t>(el->ukeys, el->n_ukeys, hp);
-                                khi = lower_bound_dev<uint64_t>(el->ukeys, el->n_ukeys, hp + R);
+                                klo = lower_bound_dev<uint64_t>(as_global(el->ukeys), el->n_ukeys, hp);
+                                khi = lower_bound_dev<uint64_t>(as_global(el->ukeys), el->n_ukeys, hp + R);
                             }
-                            const uint32_t lo = el->offs[klo], hi = el->offs[khi];
+                            const uint32_t lo = as_global(el->offs)[klo], hi = as_global(el->offs)[khi];
                             // check_last_kmer, :90-112: offsets n-k+i, i in [1, k-m], where no k-mer
                             // starts but the query still fits.  Bit j of aux <-> position n - j.
-                            const uint8_t* __restrict__ tail = ix->tail + (ix->kmax - k);   // last k letters
+                            const KMX_GLOBAL uint8_t* tail = as_global(ix->tail) + (ix->kmax - k);   // last k letters
                             uint64_t tmask = 0;
                             for (uint32_t i = 1; i + m <= k; ++i) {
                                 bool eq = true;
@@ -231,7 +257,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                 Run r{0, 0};
                 const uint32_t nparts = pe.nparts;
                 for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
-                    const KmxPlanEntry e = ix->plan[mm];
+                    const KmxPlanEntry e = load_plan(ix, mm);
                     const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
                     const uint32_t k = el->k;
                     mm -= k;                                  // this summand covers [mm, mm + k)
@@ -286,7 +312,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     __syncthreads();
 
     if (q < nq) {
-        d.src[q] = src;
+        d.src[q] = (kind == KMX_KIND_STITCH || kind == KMX_KIND_PREFIX) ? (src | SRC_SLOW) : src;
         d.cnt[q] = cnt;
         d.kind[q] = kind;
         d.status[q] = status;
@@ -315,6 +341,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 // 64 candidates = one compressed_bitset word, produced by one ballot.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
+                                                        const uint32_t* __restrict__ arena,
                                                         const uint8_t* __restrict__ qranks,
                                                         const uint64_t* __restrict__ qoff, QueryDesc d,
                                                         uint64_t n_stitch, uint64_t* __restrict__ mask_words)
@@ -322,7 +349,6 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
     const uint32_t lane = lane_id();
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
-    const uint32_t* __restrict__ arena = ix->arena;
     const uint32_t sigma = ix->sigma;
 
     for (uint64_t i = wave; i < n_stitch; i += n_waves) {
@@ -331,10 +357,10 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         const uint64_t m = qoff[q + 1] - b;
         const uint8_t* __restrict__ qr = qranks + b;
         const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q];
+        const uint64_t src = d.src[q] & ~SRC_SLOW;
         uint64_t* __restrict__ words = mask_words + d.aux[q];
         const uint32_t n_words = c0 / 64 + 1;                          // compressed_bitset.hpp:23
-        const KmxPlanEntry pe = ix->plan[m];
+        const KmxPlanEntry pe = load_plan(ix, m);
 
         // parts beyond the first one
         uint32_t n_extra, sk = 0, sP = 0;
@@ -366,7 +392,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
             } else {
                 // the walk is serial and wave-uniform; lane s keeps step s
                 for (uint32_t s = 0; s < chunk; ++s) {
-                    const KmxPlanEntry e = ix->plan[mm];
+                    const KmxPlanEntry e = load_plan(ix, mm);
                     const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
                     const uint32_t k = el->k;
                     mm -= k;                                           // this summand covers [mm, mm + k)
@@ -530,26 +556,37 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_partition(const uint64_t* __restr
 //   3. slot s then copies arena[rec[f] + (s - f)] -> out[tile_base + s]: reads follow
 //      the bucket runs (contiguous inside a run), writes are fully coalesced.
 // ---------------------------------------------------------------------------
-#define REC_SLOW (uint64_t(1) << 63)
 
-template <int E>
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load at 4-byte alignment
+typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
+
+// rec_t = uint32_t when every arena index fits 31 bits (the usual case: LDS 16 KB/tile of 2048),
+// uint64_t otherwise.  The top bit flags the slow path and the rest then is q - qa.
+template <typename rec_t>
+struct RecTraits {
+    static constexpr rec_t SLOW = rec_t(1) << (sizeof(rec_t) * 8 - 1);
+};
+
+template <int E, bool VEC, bool NT, typename rec_t>
 __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restrict__ ix,
+                                                    const uint32_t* __restrict__ arena,
                                                     const uint64_t* __restrict__ hit_off,
                                                     const uint32_t* __restrict__ tile_q, uint64_t total,
                                                     QueryDesc d, uint32_t* __restrict__ out)
 {
     constexpr int TILE = KMX_BLOCK * E;
+    constexpr rec_t SLOW = RecTraits<rec_t>::SLOW;
     __shared__ __attribute__((aligned(16))) uint32_t mark[TILE];
-    __shared__ uint64_t rec[TILE];
+    __shared__ rec_t rec[TILE];
     __shared__ uint32_t wave_tot[KMX_BLOCK / KMX_WAVE];
 
     const uint32_t tid = threadIdx.x;
     const uint64_t base = uint64_t(blockIdx.x) * TILE;
     const uint64_t tile_end = min(base + uint64_t(TILE), total);
     const uint32_t qa = tile_q[blockIdx.x], qb = tile_q[blockIdx.x + 1];
-    const uint32_t* __restrict__ arena = ix->arena;
 
-    // 1. clear marks (blocked, 16-byte LDS stores)
+    // 1. clear marks (blocked, 16-byte LDS stores), then every query that owns slots of this tile
+    //    marks its first slot
     {
         uint4* m4 = reinterpret_cast<uint4*>(mark) + tid * (E / 4);
 #pragma unroll
@@ -557,14 +594,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restric
     }
     __syncthreads();
     for (uint64_t q = uint64_t(qa) + tid; q <= qb; q += KMX_BLOCK) {
+        // three independent loads, issued together
         const uint64_t s = hit_off[q], e = hit_off[q + 1];
-        if (e > s && e > base && s < tile_end) {
+        const uint64_t sv = d.src[q];
+        // non-short-circuit on purpose: sv takes part so that its load is issued with the other two
+        if ((e > s) & (e > base) & (s < tile_end) & (sv != ~uint64_t(0))) {
             const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
-            const uint8_t kind = d.kind[q];
             mark[slot] = slot + 1;
-            // EXACT: rec = arena index of the element that lands in `slot` (never negative, so
-            // bit 63 stays free for the REC_SLOW flag); slot' >= slot then reads rec + (slot' - slot)
-            rec[slot] = (kind == KMX_KIND_EXACT) ? (d.src[q] + (base + slot - s)) : (REC_SLOW | q);
+            // plain bucket copy: arena index of the element that lands in `slot` (never negative)
+            rec[slot] = (sv & SRC_SLOW) ? rec_t(SLOW | rec_t(q - qa)) : rec_t(sv + (base + slot - s));
         }
     }
     __syncthreads();
@@ -603,63 +641,129 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restric
     }
     __syncthreads();
 
-    // 3. gather: strided arrangement, all loads first, then all stores
-    uint32_t val[E];
-    bool live[E];
+    // rare path: PREFIX slots (dependent loads) and STITCH slots (left to k_compact)
+    auto slow_slot = [&](uint32_t slot, uint32_t f, bool& live) -> uint32_t {
+        const uint64_t q = uint64_t(qa) + uint64_t(rec[f] & ~SLOW);
+        if (d.kind[q] != KMX_KIND_PREFIX) { live = false; return 0; }
+        // slice of every k-mer with this prefix, then the last-kmer offsets
+        // (kmer_index.hpp:138-146): bit j of aux <-> position n - j
+        const uint64_t idx = base + slot - hit_off[q];
+        const uint64_t tmask = d.aux[q];
+        const uint32_t len = d.cnt[q] - uint32_t(__popcll(tmask));
+        if (idx < len) return arena[(d.src[q] & ~SRC_SLOW) + idx];
+        uint32_t t = uint32_t(idx - len);                               // t-th smallest position = t-th highest bit
+        uint64_t mm = tmask;
+        int bit = 63 - __clzll(mm);
+        while (t--) { mm &= ~(uint64_t(1) << bit); bit = 63 - __clzll(mm); }
+        return uint32_t(ix->n - uint64_t(bit));
+    };
+
+    // 3. gather.  The common path is branch-free straight-line code so that every load of the
+    //    thread is in flight before the first store: dead or slow slots load arena[0] instead.
+    if constexpr (VEC) {
+        // thread owns quads qd = j*256 + tid, i.e. slots 4*qd .. 4*qd+3: one 16-byte load at 4-byte
+        // alignment (the arena is padded by 16 bytes) serves every slot of the quad that lies in the
+        // run of its first slot; slots of a later run get their own dword load (separate registers)
+        constexpr int NQ = E / 4;
+        u32x4_a16 v4[NQ];
+        uint32_t x[NQ][3];
+        uint32_t fq[NQ][4];
+        uint32_t livem[NQ], slowm[NQ], diffm[NQ];
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const uint32_t slot = j * KMX_BLOCK + tid;
-        live[j] = base + slot < tile_end;
-        val[j] = 0;
-        if (live[j]) {
-            const uint32_t st = mark[slot] - 1;
-#ifdef KMX_CHECKED
-            if (st >= uint32_t(TILE)) {
-                unsigned long long* dbg = ix->dbg;
-                if (atomicAdd(&dbg[0], 1ull) == 0) { dbg[1] = blockIdx.x; dbg[2] = slot; dbg[3] = st; dbg[4] = qa; dbg[5] = qb; dbg[6] = base; dbg[7] = 111; }
-                live[j] = false;
-                continue;
-            }
-#endif
-            const uint64_t r = rec[st];
-            if (!(r & REC_SLOW)) {
-#ifdef KMX_CHECKED
-                if (r + (slot - st) >= ix->arena_elems) {
-                    unsigned long long* dbg = ix->dbg;
-                    if (atomicAdd(&dbg[0], 1ull) == 0) { dbg[1] = blockIdx.x; dbg[2] = slot; dbg[3] = st; dbg[4] = qa; dbg[5] = qb; dbg[6] = r; dbg[7] = 222; }
-                    live[j] = false;
-                    continue;
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t qd = j * KMX_BLOCK + tid;
+            const uint32_t slot0 = 4 * qd;
+            const uint64_t g0 = base + slot0;
+            uint32_t lm = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) lm |= (g0 + i < tile_end) ? (1u << i) : 0u;
+            const uint4 mk = reinterpret_cast<const uint4*>(mark)[qd];
+            fq[j][0] = max(mk.x, 1u) - 1; fq[j][1] = max(mk.y, 1u) - 1; fq[j][2] = max(mk.z, 1u) - 1; fq[j][3] = max(mk.w, 1u) - 1;
+            const rec_t r0 = rec[fq[j][0]];
+            uint32_t sm = (lm & 1u) && (r0 & SLOW) ? 1u : 0u;
+            const uint64_t idx0 = ((lm & 1u) && !(r0 & SLOW)) ? uint64_t(r0 & ~SLOW) + (slot0 - fq[j][0]) : 0;
+            v4[j] = *reinterpret_cast<const u32x4_a4*>(arena + idx0);
+            uint32_t dm = 0;
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                x[j][i - 1] = 0;
+                if ((lm >> i & 1u) && fq[j][i] != fq[j][0]) {
+                    const rec_t ri = rec[fq[j][i]];
+                    if (ri & SLOW) sm |= 1u << i;
+                    else { x[j][i - 1] = arena[uint64_t(ri) + (slot0 + i - fq[j][i])]; dm |= 1u << i; }
+                } else if ((lm >> i & 1u) && (r0 & SLOW)) {
+                    sm |= 1u << i;
                 }
-#endif
-                val[j] = arena[r + (slot - st)];
-            } else {
-                const uint64_t q = r & ~REC_SLOW;
-                const uint8_t kind = d.kind[q];
-                if (kind == KMX_KIND_PREFIX) {
-                    // slice of every k-mer with this prefix, then the last-kmer offsets
-                    // (kmer_index.hpp:138-146): bit j of aux <-> position n - j
-                    const uint64_t idx = base + slot - hit_off[q];
-                    const uint64_t tmask = d.aux[q];
-                    const uint32_t len = d.cnt[q] - uint32_t(__popcll(tmask));
-                    if (idx < len) {
-                        val[j] = arena[d.src[q] + idx];
-                    } else {
-                        uint32_t t = uint32_t(idx - len);      // t-th smallest position = t-th highest bit
-                        uint64_t mm = tmask;
-                        int bit = 63 - __clzll(mm);
-                        while (t--) { mm &= ~(uint64_t(1) << bit); bit = 63 - __clzll(mm); }
-                        val[j] = uint32_t(ix->n - uint64_t(bit));
+            }
+            livem[j] = lm; slowm[j] = sm; diffm[j] = dm;
+        }
+        uint32_t any_slow = 0;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) any_slow |= slowm[j];
+        // merge: slot i takes the quad load unless it lies in a later run
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+            for (int i = 1; i < 4; ++i)
+                if (diffm[j] >> i & 1u) v4[j][i] = x[j][i - 1];
+        }
+        if (__any(any_slow != 0)) {
+#pragma unroll
+            for (int j = 0; j < NQ; ++j) {
+                const uint32_t slot0 = 4 * (j * KMX_BLOCK + tid);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (slowm[j] >> i & 1u) {
+                        bool live = true;
+                        const uint32_t val = slow_slot(slot0 + i, fq[j][i], live);
+                        v4[j][i] = val;
+                        if (!live) livem[j] &= ~(1u << i);
                     }
-                } else {
-                    live[j] = false;                           // STITCH: written by k_compact
                 }
             }
         }
-    }
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const uint32_t slot = j * KMX_BLOCK + tid;
-        if (live[j]) out[base + slot] = val[j];
+        for (int j = 0; j < NQ; ++j) {
+            const uint32_t slot0 = 4 * (j * KMX_BLOCK + tid);
+            uint32_t* dst = out + base + slot0;
+            if (livem[j] == 15u) {
+                if constexpr (NT) __builtin_nontemporal_store(v4[j], reinterpret_cast<u32x4_a16*>(dst));
+                else *reinterpret_cast<u32x4_a16*>(dst) = v4[j];
+            } else if (livem[j]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (livem[j] >> i & 1u) dst[i] = v4[j][i];
+            }
+        }
+    } else {
+        // single slots, strided arrangement
+        uint32_t val[E], fs[E];
+        bool live[E], slow[E];
+        bool any_slow = false;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t slot = j * KMX_BLOCK + tid;
+            live[j] = base + slot < tile_end;
+            fs[j] = max(mark[slot], 1u) - 1;
+            const rec_t r = rec[fs[j]];
+            slow[j] = live[j] && (r & SLOW);
+            any_slow |= slow[j];
+            const uint64_t idx = (live[j] && !(r & SLOW)) ? uint64_t(r) + (slot - fs[j]) : 0;
+            val[j] = arena[idx];
+        }
+        if (__any(any_slow)) {
+#pragma unroll
+            for (int j = 0; j < E; ++j)
+                if (slow[j]) val[j] = slow_slot(j * KMX_BLOCK + tid, fs[j], live[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            const uint32_t slot = j * KMX_BLOCK + tid;
+            if (live[j]) {
+                if constexpr (NT) __builtin_nontemporal_store(val[j], out + base + slot);
+                else out[base + slot] = val[j];
+            }
+        }
     }
 }
 
@@ -669,7 +773,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restric
 // popcount prefix per word.  One wave per query; candidates are ascending, so
 // the compacted list already is to_vector()'s sorted output.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(KMX_BLOCK) void k_compact(const KmxIndexDev* __restrict__ ix, QueryDesc d,
+__global__ __launch_bounds__(KMX_BLOCK) void k_compact(const uint32_t* __restrict__ arena, QueryDesc d,
                                                        uint64_t n_stitch,
                                                        const uint64_t* __restrict__ mask_words,
                                                        const uint64_t* __restrict__ hit_off,
@@ -678,12 +782,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_compact(const KmxIndexDev* __rest
     const uint32_t lane = lane_id();
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
-    const uint32_t* __restrict__ arena = ix->arena;
     for (uint64_t i = wave; i < n_stitch; i += n_waves) {
         const uint32_t q = d.stitch_list[i];
         if (d.cnt[q] == 0) continue;
         const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q];
+        const uint64_t src = d.src[q] & ~SRC_SLOW;
         const uint64_t* __restrict__ words = mask_words + d.aux[q];
         uint64_t o = hit_off[q];
         const uint32_t n_words = c0 / 64 + 1;
@@ -734,9 +837,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_merge_pass(const KmxIndexDev* __r
     uint32_t* __restrict__ ot = src_is_out ? tmp + poff[i] : out + hit_off[q];
 
     const uint64_t m = qoff[q + 1] - qoff[q];
-    const KmxPlanEntry pe = ix->plan[m];
+    const KmxPlanEntry pe = load_plan(ix, m);
     const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
-    const uint32_t* __restrict__ offs = el->offs + d.key[q];   // run r spans [offs[r]-offs[0], offs[r+1]-offs[0])
+    const KMX_GLOBAL uint32_t* offs = as_global(el->offs) + d.key[q];   // run r spans [offs[r]-offs[0], offs[r+1]-offs[0])
     const uint32_t n_runs = d.c0[q];
     const uint32_t o0 = offs[0];
 
@@ -785,12 +888,12 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
     hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
 }
 
-void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words)
 {
     uint64_t waves = n_stitch;
     unsigned int blocks = (unsigned int)std::min<uint64_t>((waves + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_validate, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, d, n_stitch, mask_words);
+    hipLaunchKernelGGL(k_validate, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
 }
 
 uint64_t scan_blocks(uint64_t n) { return blocks_for(n, KMX_SCAN_TILE); }
@@ -804,25 +907,51 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, 
     hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out);
 }
 
-uint64_t fill_tile() { return uint64_t(KMX_BLOCK) * KMX_FILL_E; }
+// fill variants, selected at run time (KMX_FILL_VARIANT, see kmx_capi.hip)
+uint64_t fill_tile(const FillVariant& v) { return uint64_t(KMX_BLOCK) * v.e; }
 
-void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t n_tiles, uint32_t* tile_q)
+void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q)
 {
-    hipLaunchKernelGGL(k_partition, dim3(blocks_for(n_tiles + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, off, nq,
-                       fill_tile(), n_tiles, tile_q);
+    hipLaunchKernelGGL(k_partition, dim3(blocks_for(n_tiles + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, off, nq, tile, n_tiles, tile_q);
 }
 
-void launch_fill(hipStream_t s, const KmxIndexDev* ix, const uint64_t* hit_off, const uint32_t* tile_q,
-                 uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
+template <int E, bool VEC, bool NT>
+static void launch_fill_rec(hipStream_t s, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off, const uint32_t* tile_q,
+                            uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
 {
-    hipLaunchKernelGGL(k_fill<KMX_FILL_E>, dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, hit_off, tile_q, total, d, out);
+    if (rec32)
+        hipLaunchKernelGGL((k_fill<E, VEC, NT, uint32_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
+    else
+        hipLaunchKernelGGL((k_fill<E, VEC, NT, uint64_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
 }
 
-void launch_compact(hipStream_t s, const KmxIndexDev* ix, const QueryDesc& d, uint64_t n_stitch,
+void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
+                 const uint32_t* tile_q, uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
+{
+#define KMX_FILL_CASE(E_, VEC_, NT_)                                                                   \
+    if (v.e == E_ && v.vec == VEC_ && v.nt == NT_) {                                                   \
+        launch_fill_rec<E_, VEC_, NT_>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);          \
+        return;                                                                                        \
+    }
+    KMX_FILL_CASE(8, false, false)
+    KMX_FILL_CASE(8, false, true)
+    KMX_FILL_CASE(8, true, false)
+    KMX_FILL_CASE(8, true, true)
+    KMX_FILL_CASE(16, false, false)
+    KMX_FILL_CASE(16, false, true)
+    KMX_FILL_CASE(4, false, false)
+    KMX_FILL_CASE(4, false, true)
+    KMX_FILL_CASE(12, false, false)
+    KMX_FILL_CASE(12, false, true)
+#undef KMX_FILL_CASE
+    launch_fill_rec<8, false, false>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);
+}
+
+void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,
                     const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out)
 {
     unsigned int blocks = (unsigned int)std::min<uint64_t>((n_stitch + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_compact, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, d, n_stitch, mask_words, hit_off, out);
+    hipLaunchKernelGGL(k_compact, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, arena, d, n_stitch, mask_words, hit_off, out);
 }
 
 void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen)
