@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--sigma", type=int, default=4)
     ap.add_argument("--nq", type=int, default=10_000_000, help="queries per GPU per step")
     ap.add_argument("--table", choices=["open", "dense", "auto"], default="open")
+    ap.add_argument("--gather", choices=["totals", "hits"], default="totals",
+                    help="totals: hit lists stay sharded where they were produced, per-shard totals exchanged after the timed region "
+                         "(default, zero data-path collective); hits: RCCL gatherv of every hit list to rank 0 inside each step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
@@ -40,6 +43,7 @@ def main():
 
     import torch
     import torch.distributed as dist
+    from kmer_index_amd import dist as kdist
     from kmer_index_amd import engine, synth
 
     rank = int(os.environ.get("RANK", "0"))
@@ -87,6 +91,9 @@ def main():
 
     def step():
         idx.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=stream, result=res)
+        if world > 1 and args.gather == "hits":
+            t_off, t_pos = res.device_tensors(dev)
+            kdist.gather_hit_lists(t_off, t_pos, dst=0)
 
     for _ in range(args.warmup):
         step()
@@ -108,12 +115,12 @@ def main():
     counts = res.counts()
 
     t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    t_hits = torch.tensor([counts["n_hits"]], dtype=torch.int64, device=dev)
+    total_hits = counts["n_hits"]
     if world > 1:
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t_hits, op=dist.ReduceOp.SUM)          # the one exchange: per-shard hit totals
+        totals = kdist.all_gather_totals(nq, counts["n_hits"], device=dev)    # the one exchange: per-shard totals
+        total_hits = int(totals[:, 1].sum())
     elapsed = float(t_el.item())
-    total_hits = int(t_hits.item())
 
     # ---- verification of a sample against the CPU oracle (after the timed region) ----
     verified = None
@@ -159,6 +166,15 @@ def main():
         job_bytes = float(nq) * (m + 16 + 8) + 8.0 * n_hits_rank
         achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
         kernels_ms = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items() if v["launches"]}
+        # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 --pmc
+        # FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction) — only when the workload matches it.
+        traffic, traffic_src = None, None
+        try:
+            prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_current.json")))
+            if prof["k_fill"]["algorithmic_bytes_per_launch"] == int(fill_bytes):
+                traffic, traffic_src = prof["k_fill"]["hbm_bytes_per_launch"], "profiles/pmc_summary_current.json"
+        except Exception:
+            pass
         out = {
             "metric": "M queries/sec, DNA4 k=10 exact-match batch search, 1e8-bp text",
             "value": round(value, 3),
@@ -175,9 +191,9 @@ def main():
             "config": {"workload": f"BASELINE configs[1]: DNA4 text {args.n} bp, k={args.k}, {nq} uniform random {m}-mer queries per GPU per step, "
                                    f"materialised sorted position lists (to_vector), table={args.table}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
-                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated"},
+                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated", "gather": args.gather},
             "roofline": {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),
                          "job_algorithmic_GBps": round(job_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "job_frac": round(job_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},

@@ -1,0 +1,155 @@
+// kmer::kmer_index<alphabet_t, position_t, ks...> / kmer::make_kmer_index<ks...>() — host mirror of
+// the reference's user API (kmer_index.hpp:350-579) on top of the C-ABI in include/kmx.h.
+//
+//   auto index = kmer::make_kmer_index<8, 10, 12>(text);                 // kmer_index.hpp:569-579
+//   auto hits  = index.search(query).to_vector();                        // :505-558 + result :244-260
+//   auto many  = index.search(std::vector<std::vector<dna4>>{...});      // batch overload (new)
+//
+// Same names, same argument meaning, same error behaviour: std::invalid_argument for a query that
+// is too long (:507-509) or whose sub-k fan-out exceeds 1e7 (:119-122).  All searching happens on
+// the GPU; there is no host search path.  Link with kmer_index_amd/libkmx.so.
+#pragma once
+#include <cstdint>
+#include <memory>
+#include <ranges>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <utility>
+#include <vector>
+
+#include "../kmx.h"
+#include "alphabet.hpp"
+#include "kmer_index_result.hpp"
+
+namespace kmer
+{
+    namespace detail
+    {
+        inline void throw_on(kmx_status st, const char* what)
+        {
+            if (st == KMX_OK) return;
+            std::string msg = std::string(what) + ": " + kmx_last_error();
+            if (st == KMX_ERR_INVALID_ARGUMENT || st == KMX_ERR_TOO_LARGE) throw std::invalid_argument(msg);
+            throw std::runtime_error(msg);
+        }
+
+        struct result_deleter { void operator()(kmx_result* r) const { kmx_result_free(r); } };
+        struct index_deleter { void operator()(kmx_index* i) const { kmx_index_free(i); } };
+    } // namespace detail
+
+    template<typename alphabet_t, typename position_t, std::size_t... ks>
+    class kmer_index
+    {
+        static_assert(sizeof...(ks) > 0 && sizeof...(ks) <= KMX_MAX_KS, "between 1 and KMX_MAX_KS values of k");
+        static_assert(std::is_same_v<position_t, std::uint32_t>, "the engine stores positions as uint32_t (make_kmer_index, kmer_index.hpp:575)");
+        static_assert((detail::k_is_valid(detail::alphabet_traits<alphabet_t>::size, ks) && ...),
+                      "the hashspace for the current k cannot be represented with only a 64-bit integer. Please specify a valid k");
+
+        using traits = detail::alphabet_traits<alphabet_t>;
+        std::unique_ptr<kmx_index, detail::index_deleter> _index;
+        const std::uint32_t* _arena = nullptr;
+        std::size_t _query_size_range = KMX_QUERY_SIZE_RANGE;
+
+    public:
+        using result_t = detail::kmer_index_result<position_t>;
+
+        // kmer_index.hpp:480-496 — one flattened element per k (built on n_threads host threads) + planner
+        template<std::ranges::range text_t>
+        kmer_index(text_t& text, std::size_t n_threads = std::max(std::thread::hardware_concurrency(), 1u))
+        {
+            std::vector<std::uint8_t> ranks;
+            ranks.reserve(std::ranges::size(text));
+            for (auto const& l : text) ranks.push_back(traits::to_rank(l));
+            const std::uint32_t k_arr[] = {std::uint32_t(ks)...};
+            kmx_options opts{};
+            opts.struct_size = sizeof(kmx_options);
+            opts.device = -1;
+            opts.n_threads = std::uint32_t(n_threads);
+            opts.keep_host_arena = 1;
+            kmx_index* raw = nullptr;
+            detail::throw_on(kmx_index_build(ranks.data(), ranks.size(), std::uint32_t(traits::size), k_arr, sizeof...(ks), &opts, &raw),
+                             "kmer_index");
+            _index.reset(raw);
+            std::uint64_t n_elems = 0;
+            detail::throw_on(kmx_index_arena_host(raw, &_arena, &n_elems), "kmer_index");
+        }
+
+        // kmer_index.hpp:498-502
+        void extend_query_size_range(std::size_t new_maximum)
+        {
+            detail::throw_on(kmx_index_extend_query_size_range(_index.get(), std::uint32_t(new_maximum)), "extend_query_size_range");
+            _query_size_range = new_maximum;
+        }
+
+        // batch search: one GPU pass over all queries; results share the batch's buffers
+        std::vector<result_t> search(const std::vector<std::vector<alphabet_t>>& queries) const
+        {
+            std::vector<std::uint8_t> ranks;
+            std::vector<std::uint64_t> off(queries.size() + 1, 0);
+            for (std::size_t i = 0; i < queries.size(); ++i) off[i + 1] = off[i] + queries[i].size();
+            ranks.reserve(off.back());
+            for (auto const& q : queries)
+                for (auto const& l : q) ranks.push_back(traits::to_rank(l));
+
+            kmx_result* raw = nullptr;
+            detail::throw_on(kmx_search_batch(_index.get(), ranks.data(), off.data(), queries.size(), KMX_SEARCH_KEEP_MASKS, &raw), "search");
+            std::shared_ptr<kmx_result> handle(raw, detail::result_deleter{});
+            const std::uint64_t* hit_off; const std::uint32_t* positions; const std::uint8_t* status; const std::uint8_t* kinds;
+            detail::throw_on(kmx_result_view(raw, &hit_off, &positions, &status, &kinds), "search");
+            const std::uint64_t* mask_base; const std::uint64_t* mask_words; const std::uint32_t* cand_count; const std::uint64_t* cand_src;
+            detail::throw_on(kmx_result_masks(raw, &mask_base, &mask_words, &cand_count, &cand_src), "search");
+
+            std::vector<result_t> out;
+            out.reserve(queries.size());
+            for (std::size_t i = 0; i < queries.size(); ++i)
+            {
+                switch (status[i])
+                {
+                    case KMX_Q_OK: break;
+                    case KMX_Q_TOO_LONG:       // kmer_index.hpp:507-509
+                        throw std::invalid_argument("query size exceed the maximum size " + std::to_string(_query_size_range) + " specified");
+                    case KMX_Q_SUBK_FANOUT:    // kmer_index.hpp:119-122
+                        throw std::invalid_argument("query size too low for specified k");
+                    case KMX_Q_EMPTY_QUERY:    // assert(query.size() > 0), kmer_index.hpp:195
+                        throw std::invalid_argument("query must not be empty");
+                    default:
+                        throw std::invalid_argument("query holds a letter outside the alphabet");
+                }
+                const position_t* hits = positions ? positions + hit_off[i] : nullptr;
+                const std::size_t n_hits = std::size_t(hit_off[i + 1] - hit_off[i]);
+                if (kinds[i] == KMX_KIND_STITCH)
+                    out.emplace_back(handle, hits, n_hits, _arena + cand_src[i], std::size_t(cand_count[i]), mask_words + mask_base[i]);
+                else if (kinds[i] == KMX_KIND_NONE)
+                    out.emplace_back();
+                else
+                    out.emplace_back(handle, hits, n_hits);
+            }
+            return out;
+        }
+
+        // kmer_index.hpp:505-558
+        result_t search(std::vector<alphabet_t>& query) const
+        {
+            return std::move(search(std::vector<std::vector<alphabet_t>>{query}).front());
+        }
+
+        // kmer_index.hpp:561-565 (the reference forgets the return)
+        result_t search(std::vector<alphabet_t>&& query) const
+        {
+            auto hold = std::move(query);
+            return search(hold);
+        }
+
+        const kmx_index* handle() const { return _index.get(); }
+    };
+
+    // kmer_index.hpp:569-579
+    template<std::size_t... ks, std::ranges::range text_t>
+    auto make_kmer_index(text_t&& text, std::size_t n_threads = std::thread::hardware_concurrency())
+    {
+        using alphabet_t = std::remove_cvref_t<std::ranges::range_value_t<text_t>>;
+        using position_t = std::uint32_t;
+        return kmer_index<alphabet_t, position_t, ks...>(text, std::max<std::size_t>(n_threads, 1));
+    }
+} // namespace kmer

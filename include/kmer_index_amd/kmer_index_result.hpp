@@ -1,0 +1,70 @@
+// kmer::detail::kmer_index_result — host mirror of the reference's result view
+// (kmer_index_result.hpp:15-272).
+//
+// Reference: pointers to the index's bucket vectors + a compressed_bitset + a bypass flag;
+// to_vector() copies the valid positions and sorts them.  Here the engine has already
+// materialised to_vector() on the GPU, so a result is a window into the batch's hit buffer
+// (kept alive by a shared handle) and, for cross-referenced queries, the candidate run (a window
+// into the index's host arena) plus the mask words.  Observable differences, all documented
+// reference defects:
+//   * size() returns the number of valid positions (the reference counts mask bits and so
+//     returns 0 for bypass and sub-k results, kmer_index_result.hpp:239-242);
+//   * begin()/end() work (the reference's iterator does not instantiate, :182).
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <iterator>
+#include <memory>
+#include <vector>
+
+#include "compressed_bitset.hpp"
+
+namespace kmer::detail
+{
+    enum class BYPASS_BITMASK : bool { YES = true, NO = false };
+
+    template<typename position_t>
+    class kmer_index_result
+    {
+        std::shared_ptr<void> _keep_alive;              // the batch result handle the windows point into
+        const position_t* _hits = nullptr;              // ascending valid positions (= to_vector())
+        std::size_t _n_hits = 0;
+        const position_t* _candidates = nullptr;        // first part's bucket (only for masked results)
+        std::size_t _n_candidates = 0;
+        compressed_bitset<std::uint_fast64_t> _bitmask; // validity over the candidates
+        bool _bypass_bitmask = true;
+
+    public:
+        using const_iterator = const position_t*;
+
+        kmer_index_result() : _bitmask(0, true), _bypass_bitmask(false) {}
+
+        kmer_index_result(std::shared_ptr<void> keep, const position_t* hits, std::size_t n_hits)
+            : _keep_alive(std::move(keep)), _hits(hits), _n_hits(n_hits), _bitmask(0, true), _bypass_bitmask(true)
+        {}
+
+        kmer_index_result(std::shared_ptr<void> keep, const position_t* hits, std::size_t n_hits,
+                          const position_t* candidates, std::size_t n_candidates, const std::uint64_t* mask_words)
+            : _keep_alive(std::move(keep)), _hits(hits), _n_hits(n_hits), _candidates(candidates), _n_candidates(n_candidates),
+              _bitmask(n_candidates, mask_words), _bypass_bitmask(false)
+        {}
+
+        // number of valid positions
+        std::size_t size() const { return _n_hits; }
+        bool empty() const { return _n_hits == 0; }
+
+        // kmer_index_result.hpp:244-260
+        std::vector<position_t> to_vector() const { return std::vector<position_t>(_hits, _hits + _n_hits); }
+
+        const_iterator begin() const { return _hits; }
+        const_iterator end() const { return _hits + _n_hits; }
+        position_t at(std::size_t i) const { return to_vector().at(i); }
+
+        // the zero-copy view of the reference: candidates + validity mask
+        bool bypasses_bitmask() const { return _bypass_bitmask; }
+        std::size_t n_candidates() const { return _bypass_bitmask ? _n_hits : _n_candidates; }
+        const position_t* candidates() const { return _bypass_bitmask ? _hits : _candidates; }
+        bool is_valid(std::size_t i) const { return _bypass_bitmask ? true : _bitmask.at(i); }
+        const compressed_bitset<std::uint_fast64_t>& bitmask() const { return _bitmask; }
+    };
+} // namespace kmer::detail

@@ -108,6 +108,11 @@ kmx_status kmx_index_info(const kmx_index* index, uint64_t* n, uint32_t* sigma, 
                           uint32_t* ks /* KMX_MAX_KS */, uint32_t* table_kinds /* KMX_MAX_KS */,
                           uint64_t* device_bytes);
 
+/* kmer_index::extend_query_size_range(new_maximum) (kmer_index.hpp:498-502): rebuilds the planner
+ * table for query lengths < new_maximum and installs it.  Must not run concurrently with a search
+ * on the same index. */
+kmx_status kmx_index_extend_query_size_range(kmx_index* index, uint32_t new_maximum);
+
 /* Planner tables — kmer_index::_optimal_nk_sum / _use_multi_search_scheme
  * (kmer_index.hpp:404-405) as built by choose_search_scheme (:407-476).  Pure host
  * code; usable without a device.  nk_off has range+1 entries into nk_flat; returns

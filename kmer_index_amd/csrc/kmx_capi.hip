@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -401,6 +402,23 @@ kmx_status kmx_index_info(const kmx_index* ix, uint64_t* n, uint32_t* sigma, uin
         if (table_kinds) table_kinds[i] = ix->table_kinds[i];
     }
     if (device_bytes) *device_bytes = ix->device_bytes;
+    return KMX_OK;
+}
+
+kmx_status kmx_index_extend_query_size_range(kmx_index* ix, uint32_t new_maximum)
+{
+    if (!ix || new_maximum == 0 || new_maximum > 65535 * 9u)
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_extend_query_size_range: bad argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, new_maximum);
+    const KmxPlanEntry* d_plan = nullptr;
+    kmx_status st = upload(ix, plan.data(), plan.size(), &d_plan);
+    if (st != KMX_OK) return st;
+    // patch the two header fields in place (the old table stays allocated until the index is freed)
+    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(ix->d_index) + offsetof(KmxIndexDev, plan), &d_plan, sizeof(d_plan), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(ix->d_index) + offsetof(KmxIndexDev, range), &new_maximum, sizeof(new_maximum), hipMemcpyHostToDevice));
+    ix->range = new_maximum;
     return KMX_OK;
 }
 

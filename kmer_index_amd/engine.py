@@ -19,7 +19,7 @@ Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
 
 # every symbol include/kmx.h declares
 EXPORTS = [
-    "kmx_index_build", "kmx_index_free", "kmx_index_info", "kmx_index_arena_host", "kmx_plan", "kmx_fast_pow",
+    "kmx_index_build", "kmx_index_free", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_plan", "kmx_fast_pow",
     "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
@@ -62,6 +62,8 @@ def lib():
         L.kmx_index_info.argtypes = [vp, P(u64), P(u32), P(u32), vp, vp, P(u64)]
         L.kmx_index_arena_host.restype = C.c_int
         L.kmx_index_arena_host.argtypes = [vp, P(vp), P(u64)]
+        L.kmx_index_extend_query_size_range.restype = C.c_int
+        L.kmx_index_extend_query_size_range.argtypes = [vp, u32]
         L.kmx_plan.restype = C.c_int
         L.kmx_plan.argtypes = [vp, u32, u32, vp, vp, vp, u64, P(u64)]
         L.kmx_fast_pow.restype = u64
@@ -150,6 +152,20 @@ class Result:
         _check(lib().kmx_result_view_device(self._h, C.byref(a), C.byref(b), C.byref(s)))
         return a.value, b.value, s.value
 
+    def device_tensors(self, device):
+        """(hit_off int64 [nq+1], positions int32 [n_hits]) as torch tensors aliasing the result's HBM buffers."""
+        import torch
+
+        class _Arr:
+            def __init__(self, ptr, n, typestr):
+                self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+        c = self.counts()
+        a, b, _ = self.device_ptrs()
+        t_off = torch.as_tensor(_Arr(a, c["nq"] + 1, "<i8"), device=device)
+        t_pos = torch.as_tensor(_Arr(b, c["n_hits"], "<i4"), device=device) if c["n_hits"] else torch.empty(0, dtype=torch.int32, device=device)
+        return t_off, t_pos
+
     def masks(self):
         c = self.counts()
         a, b, cc, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -200,6 +216,9 @@ class Index:
         _check(lib().kmx_index_info(self._h, C.byref(n), C.byref(sigma), C.byref(nks), ks.ctypes.data, tk.ctypes.data, C.byref(dbytes)))
         return {"n": n.value, "sigma": sigma.value, "ks": ks[:nks.value].tolist(), "tables": tk[:nks.value].tolist(),
                 "device_bytes": dbytes.value}
+
+    def extend_query_size_range(self, new_maximum):
+        _check(lib().kmx_index_extend_query_size_range(self._h, new_maximum))
 
     def arena_host(self):
         p, n = C.c_void_p(), C.c_uint64()

@@ -1,0 +1,120 @@
+// Drop-in check of the C++ host mirror: code shaped like the reference's own test
+// (test_main.cpp:21-69 — build single-k and multi-k indices, compare search(q).to_vector() with the
+// exact occurrence list for query sizes around k) compiled against include/kmer_index_amd/ and run
+// on the GPU.  Ground truth is a naive scan (the reference uses seqan3::fm_index, absent here).
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include <kmer_index_amd/kmer_index.hpp>
+
+using kmer::alphabet::aa20;
+using kmer::alphabet::dna4;
+using kmer::alphabet::dna15;
+
+static std::uint64_t mix64(std::uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+
+template<typename alphabet_t>
+std::vector<alphabet_t> generate_sequence(std::uint64_t seed, std::size_t length)
+{
+    std::vector<alphabet_t> out(length);
+    for (std::size_t i = 0; i < length; ++i)
+        out[i].assign_rank(std::uint8_t(((mix64(seed + (i + 1) * 0x9E3779B97F4A7C15ull) >> 32) * alphabet_t::alphabet_size) >> 32));
+    return out;
+}
+
+template<typename alphabet_t>
+std::vector<std::uint32_t> naive(const std::vector<alphabet_t>& text, const std::vector<alphabet_t>& q)
+{
+    std::vector<std::uint32_t> out;
+    if (q.empty() || q.size() > text.size()) return out;
+    for (std::size_t p = 0; p + q.size() <= text.size(); ++p)
+    {
+        bool eq = true;
+        for (std::size_t j = 0; j < q.size() && eq; ++j) eq = text[p + j] == q[j];
+        if (eq) out.push_back(std::uint32_t(p));
+    }
+    return out;
+}
+
+static int failures = 0;
+#define CHECK(cond) do { if (!(cond)) { std::printf("CHECK failed: %s (line %d)\n", #cond, __LINE__); ++failures; } } while (0)
+
+template<typename alphabet_t, std::size_t k>
+void run_test(std::size_t text_size, std::uint64_t seed)
+{
+    auto text = generate_sequence<alphabet_t>(seed, text_size);
+    auto single_kmer = kmer::make_kmer_index<k>(text);
+    auto multi_kmer = kmer::make_kmer_index<k, k + 1, k + 2>(text);
+
+    std::vector<std::vector<alphabet_t>> queries;
+    for (std::size_t query_size = (k > 5 ? k - 5 : 1); query_size < 2 * k; query_size++)
+    {
+        queries.push_back(generate_sequence<alphabet_t>(seed * 131 + query_size, query_size));               // random
+        std::size_t s = (seed * 7919 + query_size * 104729) % (text_size - query_size);
+        queries.emplace_back(text.begin() + s, text.begin() + s + query_size);                                // planted
+        queries.emplace_back(text.end() - query_size - (query_size % 3), text.end() - (query_size % 3));      // tail
+    }
+    // one query at a time (the reference's call shape) ...
+    for (auto& query : queries)
+    {
+        auto truth = naive(text, query);
+        CHECK(single_kmer.search(query).to_vector() == truth);
+        CHECK(multi_kmer.search(query).to_vector() == truth);
+    }
+    // ... and the batch overload
+    auto batch = multi_kmer.search(queries);
+    CHECK(batch.size() == queries.size());
+    for (std::size_t i = 0; i < queries.size(); ++i)
+    {
+        auto truth = naive(text, queries[i]);
+        CHECK(batch[i].to_vector() == truth);
+        CHECK(batch[i].size() == truth.size());
+        std::vector<std::uint32_t> via_iter(batch[i].begin(), batch[i].end());
+        CHECK(via_iter == truth);
+        if (!batch[i].bypasses_bitmask())
+        {
+            // zero-copy view: candidates filtered by the mask == to_vector()
+            std::vector<std::uint32_t> filtered;
+            for (std::size_t c = 0; c < batch[i].n_candidates(); ++c)
+                if (batch[i].is_valid(c)) filtered.push_back(batch[i].candidates()[c]);
+            CHECK(filtered == truth);
+            CHECK(batch[i].bitmask().count_bits_equal_to(true) == truth.size());
+        }
+    }
+}
+
+int main()
+{
+    run_test<dna4, 10>(200000, 1);
+    run_test<dna4, 5>(50000, 2);
+    run_test<dna15, 5>(100000, 3);
+    run_test<aa20, 4>(100000, 4);
+
+    // error behaviour of the reference: std::invalid_argument (kmer_index.hpp:507-509, :119-122)
+    {
+        auto text = generate_sequence<dna4>(9, 100000);
+        auto index = kmer::make_kmer_index<13>(text);
+        bool threw = false;
+        try { std::vector<dna4> q(10001); index.search(q); } catch (const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
+        threw = false;
+        try { std::vector<dna4> q(text.begin(), text.begin() + 1); index.search(q); } catch (const std::invalid_argument&) { threw = true; }
+        CHECK(threw);                                   // 4^12 > 1e7 buckets
+        std::vector<dna4> ok(text.begin() + 5, text.begin() + 7);
+        CHECK(index.search(ok).to_vector() == naive(text, ok));
+        CHECK(index.search(std::vector<dna4>(text.begin() + 50, text.begin() + 63)).size() >= 1);   // rvalue overload returns
+        // extend_query_size_range (kmer_index.hpp:498-502)
+        index.extend_query_size_range(20000);
+        std::vector<dna4> longq(text.begin() + 100, text.begin() + 100 + 15000);
+        auto r = index.search(longq).to_vector();
+        CHECK(r.size() >= 1 && r.front() == 100);
+    }
+    if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
+    std::printf("host api ok\n");
+    return 0;
+}
