@@ -53,11 +53,17 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)          # (== local_rank on a real N-GPU node)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("KMX_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N ranks on one GPU
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     def log(*a):
         if rank == 0:
@@ -68,7 +74,7 @@ def main():
     log(f"text n={args.n} sigma={args.sigma} generated in {time.time() - t0:.1f}s")
     t0 = time.time()
     table = {"open": engine.TABLE_OPEN, "dense": engine.TABLE_DENSE, "auto": engine.TABLE_AUTO}[args.table]
-    idx = engine.Index(text, args.sigma, [args.k], table=table, device=local_rank)
+    idx = engine.Index(text, args.sigma, [args.k], table=table, device=dev_index)
     info = idx.info()
     log(f"index built+uploaded in {time.time() - t0:.1f}s: {info}")
 

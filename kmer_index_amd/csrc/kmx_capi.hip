@@ -132,7 +132,7 @@ struct kmx_index {
     KmxIndexDev* d_index = nullptr;     // device copy of the header
     const uint32_t* d_arena = nullptr;  // the position arena (also in the header; passed to kernels directly)
     unsigned long long* d_dbg = nullptr; // KMX_CHECKED violation records
-    kmx::FillVariant fill_variant{8, false, true};   // 2048-slot tiles, dword gathers, non-temporal stores
+    kmx::FillVariant fill_variant{12, true};   // 3072-slot tiles (12 gathers in flight per thread), non-temporal stores
     bool rec32 = true;                   // every arena index fits 31 bits
     std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
     hipStream_t stream = nullptr;       // internal stream of the host-buffer search form
@@ -333,11 +333,11 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         ix->d_arena = h.arena;
     }
     h.arena_elems = arena_elems;
-    ix->rec32 = arena_elems < (uint64_t(1) << 31);
+    ix->rec32 = (arena_elems + 65536) * 4 < (uint64_t(1) << 32);   // 32-bit byte offsets reach the whole arena
     if (const char* fvs = getenv("KMX_FILL_VARIANT")) {
-        // tuning knob: "<e>[v][n]", e.g. "8v", "16vn", "8"
+        // tuning knob: "<e>[n]", e.g. "8n", "16", "16n"
         int e = atoi(fvs);
-        if (e == 4 || e == 8 || e == 12 || e == 16) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'v') != nullptr, strchr(fvs, 'n') != nullptr};
+        if (e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'n') != nullptr};
     }
     {
         void* p = nullptr;

@@ -27,11 +27,10 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
 uint64_t scan_blocks(uint64_t n);
 void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
                  unsigned long long* total_out);
-// k_fill build variants: e = output slots per thread (tile = 256 * e), vec = 16-byte quads,
-// nt = non-temporal stores of the hit lists.
+// k_fill build variants: e = output slots per thread (tile = 256 * e), nt = non-temporal stores
+// of the hit lists.
 struct FillVariant {
     int e;
-    bool vec;
     bool nt;
 };
 uint64_t fill_tile(const FillVariant& v);

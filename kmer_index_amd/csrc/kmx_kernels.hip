@@ -557,18 +557,19 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_partition(const uint64_t* __restr
 //      the bucket runs (contiguous inside a run), writes are fully coalesced.
 // ---------------------------------------------------------------------------
 
-typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));    // 16-byte load at 4-byte alignment
-typedef uint32_t u32x4_a16 __attribute__((ext_vector_type(4), aligned(16)));
-
-// rec_t = uint32_t when every arena index fits 31 bits (the usual case: LDS 16 KB/tile of 2048),
-// uint64_t otherwise.  The top bit flags the slow path and the rest then is q - qa.
+// rec_t = uint32_t when every arena index fits 31 bits (the usual case), uint64_t otherwise.
 template <typename rec_t>
 struct RecTraits {
     static constexpr rec_t SLOW = rec_t(1) << (sizeof(rec_t) * 8 - 1);
 };
 
-template <int E, bool VEC, bool NT, typename rec_t>
-__global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restrict__ ix,
+// One LDS word per output slot.  A query that owns slots of the tile writes, at its first slot f,
+//     v = (arena index of the element that belongs in slot f) + (TILE - f)      (>= 1, top bit clear)
+// or, for a query that is not a plain bucket copy, SLOW | (q - qa).  A "copy the last non-zero
+// word" scan then hands every slot s its owner's word, and the element for s is
+//     arena[v - TILE + s].
+template <int E, bool NT, typename rec_t>
+__global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : (E <= 16 ? 6 : 4))) void k_fill(const KmxIndexDev* __restrict__ ix,
                                                     const uint32_t* __restrict__ arena,
                                                     const uint64_t* __restrict__ hit_off,
                                                     const uint32_t* __restrict__ tile_q, uint64_t total,
@@ -576,21 +577,21 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restric
 {
     constexpr int TILE = KMX_BLOCK * E;
     constexpr rec_t SLOW = RecTraits<rec_t>::SLOW;
-    __shared__ __attribute__((aligned(16))) uint32_t mark[TILE];
-    __shared__ rec_t rec[TILE];
-    __shared__ uint32_t wave_tot[KMX_BLOCK / KMX_WAVE];
+    constexpr int VW = 16 / sizeof(rec_t);                     // words per 16-byte LDS access
+    typedef rec_t recv_t __attribute__((ext_vector_type(VW)));
+    __shared__ __attribute__((aligned(16))) rec_t word[TILE];
+    __shared__ rec_t wave_tot[KMX_BLOCK / KMX_WAVE];
 
     const uint32_t tid = threadIdx.x;
     const uint64_t base = uint64_t(blockIdx.x) * TILE;
     const uint64_t tile_end = min(base + uint64_t(TILE), total);
     const uint32_t qa = tile_q[blockIdx.x], qb = tile_q[blockIdx.x + 1];
 
-    // 1. clear marks (blocked, 16-byte LDS stores), then every query that owns slots of this tile
-    //    marks its first slot
+    // 1. clear (blocked, 16-byte LDS stores); then every query owning slots of this tile writes its word
     {
-        uint4* m4 = reinterpret_cast<uint4*>(mark) + tid * (E / 4);
+        recv_t* w4 = reinterpret_cast<recv_t*>(word) + tid * (E / VW);
 #pragma unroll
-        for (int j = 0; j < E / 4; ++j) m4[j] = make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < E / VW; ++j) w4[j] = recv_t(0);
     }
     __syncthreads();
     for (uint64_t q = uint64_t(qa) + tid; q <= qb; q += KMX_BLOCK) {
@@ -600,50 +601,55 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restric
         // non-short-circuit on purpose: sv takes part so that its load is issued with the other two
         if ((e > s) & (e > base) & (s < tile_end) & (sv != ~uint64_t(0))) {
             const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
-            mark[slot] = slot + 1;
-            // plain bucket copy: arena index of the element that lands in `slot` (never negative)
-            rec[slot] = (sv & SRC_SLOW) ? rec_t(SLOW | rec_t(q - qa)) : rec_t(sv + (base + slot - s));
+            word[slot] = (sv & SRC_SLOW) ? rec_t(SLOW | rec_t(q - qa)) : rec_t(sv + (base + slot - s) + (TILE - slot));
         }
     }
     __syncthreads();
 
-    // 2. max-scan of the marks in blocked arrangement
+    // 2. "last non-zero word so far" scan in blocked arrangement
     {
-        uint32_t v[E];
-        uint4* m4 = reinterpret_cast<uint4*>(mark) + tid * (E / 4);
+        rec_t v[E];
+        recv_t* w4 = reinterpret_cast<recv_t*>(word) + tid * (E / VW);
 #pragma unroll
-        for (int j = 0; j < E / 4; ++j) {
-            uint4 t = m4[j];
-            v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+        for (int j = 0; j < E / VW; ++j) {
+            const recv_t t = w4[j];
+#pragma unroll
+            for (int i = 0; i < VW; ++i) v[VW * j + i] = t[i];
         }
-        uint32_t last = 0;
+        rec_t last = 0;
 #pragma unroll
         for (int j = 0; j < E; ++j) last = v[j] ? v[j] : last;
-        // marks ascend with the slot, so "max of everything before me" = the nearest
-        // earlier lane that has a mark
+        // the nearest earlier lane that holds a word: one ballot + one cross-lane read
         const uint32_t lane = lane_id(), w = tid / KMX_WAVE;
         const uint64_t has = __ballot(last != 0);
         const uint64_t below = has & ((uint64_t(1) << lane) - 1);
         const int srcl = below ? 63 - __clzll(below) : 0;
-        uint32_t carry = __shfl(last, srcl);
+        rec_t carry = __shfl(last, srcl);
         if (!below) carry = 0;
         if (lane == KMX_WAVE - 1) wave_tot[w] = last ? last : carry;
         __syncthreads();
-        uint32_t wcarry = 0;
+        rec_t wcarry = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i)
-            if (i < w) wcarry = max(wcarry, wave_tot[i]);
-        uint32_t run = max(carry, wcarry);
+        for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i) {
+            const rec_t t = wave_tot[i];
+            if (i < w && t) wcarry = t;                         // ascending i: the nearest earlier wave wins
+        }
+        rec_t run = carry ? carry : wcarry;
 #pragma unroll
         for (int j = 0; j < E; ++j) { run = v[j] ? v[j] : run; v[j] = run; }
 #pragma unroll
-        for (int j = 0; j < E / 4; ++j) m4[j] = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+        for (int j = 0; j < E / VW; ++j) {
+            recv_t t;
+#pragma unroll
+            for (int i = 0; i < VW; ++i) t[i] = v[VW * j + i];
+            w4[j] = t;
+        }
     }
     __syncthreads();
 
     // rare path: PREFIX slots (dependent loads) and STITCH slots (left to k_compact)
-    auto slow_slot = [&](uint32_t slot, uint32_t f, bool& live) -> uint32_t {
-        const uint64_t q = uint64_t(qa) + uint64_t(rec[f] & ~SLOW);
+    auto slow_slot = [&](uint32_t slot, rec_t v, bool& live) -> uint32_t {
+        const uint64_t q = uint64_t(qa) + uint64_t(v & ~SLOW);
         if (d.kind[q] != KMX_KIND_PREFIX) { live = false; return 0; }
         // slice of every k-mer with this prefix, then the last-kmer offsets
         // (kmer_index.hpp:138-146): bit j of aux <-> position n - j
@@ -658,111 +664,56 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_fill(const KmxIndexDev* __restric
         return uint32_t(ix->n - uint64_t(bit));
     };
 
-    // 3. gather.  The common path is branch-free straight-line code so that every load of the
-    //    thread is in flight before the first store: dead or slow slots load arena[0] instead.
-    if constexpr (VEC) {
-        // thread owns quads qd = j*256 + tid, i.e. slots 4*qd .. 4*qd+3: one 16-byte load at 4-byte
-        // alignment (the arena is padded by 16 bytes) serves every slot of the quad that lies in the
-        // run of its first slot; slots of a later run get their own dword load (separate registers)
-        constexpr int NQ = E / 4;
-        u32x4_a16 v4[NQ];
-        uint32_t x[NQ][3];
-        uint32_t fq[NQ][4];
-        uint32_t livem[NQ], slowm[NQ], diffm[NQ];
+    // 3. gather, strided arrangement.  Branch-free straight-line code so that all E loads of the
+    //    thread are in flight before the first store: dead or slow slots load arena[0] instead.
+    //    Only the loaded value stays live per slot; the 32-bit variant addresses the arena with a
+    //    32-bit byte offset against the uniform base pointer (arena < 4 GiB).
+    uint32_t val[E];
+    bool any_slow = false;
+    if constexpr (sizeof(rec_t) == 4) {
+        // buffer_load with a 32-bit voffset against a wave-uniform descriptor: one address VGPR per load
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint32_t*>(arena), 0, int(uint32_t(ix->arena_elems * 4 + 64)), 0x00020000);
 #pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const uint32_t qd = j * KMX_BLOCK + tid;
-            const uint32_t slot0 = 4 * qd;
-            const uint64_t g0 = base + slot0;
-            uint32_t lm = 0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) lm |= (g0 + i < tile_end) ? (1u << i) : 0u;
-            const uint4 mk = reinterpret_cast<const uint4*>(mark)[qd];
-            fq[j][0] = max(mk.x, 1u) - 1; fq[j][1] = max(mk.y, 1u) - 1; fq[j][2] = max(mk.z, 1u) - 1; fq[j][3] = max(mk.w, 1u) - 1;
-            const rec_t r0 = rec[fq[j][0]];
-            uint32_t sm = (lm & 1u) && (r0 & SLOW) ? 1u : 0u;
-            const uint64_t idx0 = ((lm & 1u) && !(r0 & SLOW)) ? uint64_t(r0 & ~SLOW) + (slot0 - fq[j][0]) : 0;
-            v4[j] = *reinterpret_cast<const u32x4_a4*>(arena + idx0);
-            uint32_t dm = 0;
-#pragma unroll
-            for (int i = 1; i < 4; ++i) {
-                x[j][i - 1] = 0;
-                if ((lm >> i & 1u) && fq[j][i] != fq[j][0]) {
-                    const rec_t ri = rec[fq[j][i]];
-                    if (ri & SLOW) sm |= 1u << i;
-                    else { x[j][i - 1] = arena[uint64_t(ri) + (slot0 + i - fq[j][i])]; dm |= 1u << i; }
-                } else if ((lm >> i & 1u) && (r0 & SLOW)) {
-                    sm |= 1u << i;
-                }
-            }
-            livem[j] = lm; slowm[j] = sm; diffm[j] = dm;
-        }
-        uint32_t any_slow = 0;
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) any_slow |= slowm[j];
-        // merge: slot i takes the quad load unless it lies in a later run
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-#pragma unroll
-            for (int i = 1; i < 4; ++i)
-                if (diffm[j] >> i & 1u) v4[j][i] = x[j][i - 1];
-        }
-        if (__any(any_slow != 0)) {
-#pragma unroll
-            for (int j = 0; j < NQ; ++j) {
-                const uint32_t slot0 = 4 * (j * KMX_BLOCK + tid);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    if (slowm[j] >> i & 1u) {
-                        bool live = true;
-                        const uint32_t val = slow_slot(slot0 + i, fq[j][i], live);
-                        v4[j][i] = val;
-                        if (!live) livem[j] &= ~(1u << i);
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) {
-            const uint32_t slot0 = 4 * (j * KMX_BLOCK + tid);
-            uint32_t* dst = out + base + slot0;
-            if (livem[j] == 15u) {
-                if constexpr (NT) __builtin_nontemporal_store(v4[j], reinterpret_cast<u32x4_a16*>(dst));
-                else *reinterpret_cast<u32x4_a16*>(dst) = v4[j];
-            } else if (livem[j]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if (livem[j] >> i & 1u) dst[i] = v4[j][i];
-            }
+        for (int j = 0; j < E; ++j) {
+            const uint32_t slot = j * KMX_BLOCK + tid;
+            const bool live = base + slot < tile_end;
+            const uint32_t wv = word[slot];
+            const bool is_slow = (wv & SLOW) != 0;
+            any_slow |= live && is_slow;
+            const uint32_t boff = (live && !is_slow) ? ((wv - uint32_t(TILE) + slot) << 2) : 0u;
+            val[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, boff, 0, 0);
         }
     } else {
-        // single slots, strided arrangement
-        uint32_t val[E], fs[E];
-        bool live[E], slow[E];
-        bool any_slow = false;
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const uint32_t slot = j * KMX_BLOCK + tid;
-            live[j] = base + slot < tile_end;
-            fs[j] = max(mark[slot], 1u) - 1;
-            const rec_t r = rec[fs[j]];
-            slow[j] = live[j] && (r & SLOW);
-            any_slow |= slow[j];
-            const uint64_t idx = (live[j] && !(r & SLOW)) ? uint64_t(r) + (slot - fs[j]) : 0;
+            const bool live = base + slot < tile_end;
+            const rec_t wv = word[slot];
+            const bool is_slow = (wv & SLOW) != 0;
+            any_slow |= live && is_slow;
+            const uint64_t idx = (live && !is_slow) ? uint64_t(wv - rec_t(TILE) + slot) : 0;
             val[j] = arena[idx];
         }
-        if (__any(any_slow)) {
-#pragma unroll
-            for (int j = 0; j < E; ++j)
-                if (slow[j]) val[j] = slow_slot(j * KMX_BLOCK + tid, fs[j], live[j]);
-        }
+    }
+    if (__any(any_slow)) {
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const uint32_t slot = j * KMX_BLOCK + tid;
-            if (live[j]) {
-                if constexpr (NT) __builtin_nontemporal_store(val[j], out + base + slot);
-                else out[base + slot] = val[j];
+            const rec_t wv = word[slot];
+            if (base + slot < tile_end && (wv & SLOW)) {
+                bool live = true;
+                const uint32_t x = slow_slot(slot, wv, live);
+                val[j] = live ? x : 0xFFFFFFFFu;                        // 0xFFFFFFFF never is a position: "do not store"
             }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t slot = j * KMX_BLOCK + tid;
+        if (base + slot < tile_end && val[j] != 0xFFFFFFFFu) {
+            if constexpr (NT) __builtin_nontemporal_store(val[j], out + base + slot);
+            else out[base + slot] = val[j];
         }
     }
 }
@@ -915,36 +866,36 @@ void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t 
     hipLaunchKernelGGL(k_partition, dim3(blocks_for(n_tiles + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, off, nq, tile, n_tiles, tile_q);
 }
 
-template <int E, bool VEC, bool NT>
+template <int E, bool NT>
 static void launch_fill_rec(hipStream_t s, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off, const uint32_t* tile_q,
                             uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
 {
     if (rec32)
-        hipLaunchKernelGGL((k_fill<E, VEC, NT, uint32_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
+        hipLaunchKernelGGL((k_fill<E, NT, uint32_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
     else
-        hipLaunchKernelGGL((k_fill<E, VEC, NT, uint64_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
+        hipLaunchKernelGGL((k_fill<E, NT, uint64_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
 }
 
 void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
                  const uint32_t* tile_q, uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
 {
-#define KMX_FILL_CASE(E_, VEC_, NT_)                                                                   \
-    if (v.e == E_ && v.vec == VEC_ && v.nt == NT_) {                                                   \
-        launch_fill_rec<E_, VEC_, NT_>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);          \
+#define KMX_FILL_CASE(E_, NT_)                                                                         \
+    if (v.e == E_ && v.nt == NT_) {                                                                    \
+        launch_fill_rec<E_, NT_>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);         \
         return;                                                                                        \
     }
-    KMX_FILL_CASE(8, false, false)
-    KMX_FILL_CASE(8, false, true)
-    KMX_FILL_CASE(8, true, false)
-    KMX_FILL_CASE(8, true, true)
-    KMX_FILL_CASE(16, false, false)
-    KMX_FILL_CASE(16, false, true)
-    KMX_FILL_CASE(4, false, false)
-    KMX_FILL_CASE(4, false, true)
-    KMX_FILL_CASE(12, false, false)
-    KMX_FILL_CASE(12, false, true)
+    KMX_FILL_CASE(4, false)
+    KMX_FILL_CASE(4, true)
+    KMX_FILL_CASE(8, false)
+    KMX_FILL_CASE(8, true)
+    KMX_FILL_CASE(12, false)
+    KMX_FILL_CASE(12, true)
+    KMX_FILL_CASE(16, false)
+    KMX_FILL_CASE(16, true)
+    KMX_FILL_CASE(24, true)
+    KMX_FILL_CASE(32, true)
 #undef KMX_FILL_CASE
-    launch_fill_rec<8, false, false>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);
+    launch_fill_rec<8, true>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);
 }
 
 void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,

@@ -23,12 +23,18 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--table", default="open")
+    ap.add_argument("--query-order", default="random", choices=["random", "sorted"],
+                    help="sorted: queries pre-sorted by rank-hash on the host (experiment: upper bound of key-ordered processing)")
     args = ap.parse_args()
     import torch
     from kmer_index_amd import engine, synth
     dev = torch.device("cuda", 0)
     text = synth.ranks(1002, args.n, args.sigma)
     q, off = synth.uniform_queries(2002, args.nq, args.k, args.sigma)
+    if args.query_order == "sorted":
+        w = (args.sigma ** np.arange(args.k - 1, -1, -1)).astype(np.uint64)
+        h = (q.reshape(-1, args.k).astype(np.uint64) * w).sum(axis=1)
+        q = q.reshape(-1, args.k)[np.argsort(h, kind="stable")].reshape(-1).copy()
     d_q = torch.from_numpy(q).to(dev)
     d_off = torch.from_numpy(off.view(np.int64)).to(dev)
     table = {"open": engine.TABLE_OPEN, "dense": engine.TABLE_DENSE}[args.table]
@@ -66,6 +72,7 @@ def main():
     for v in variants:
         dts = sorted(x[0] for x in best[v])
         fl = sorted(x[1] for x in best[v])
+        kms = {k: round(x["total_ms"] / max(x["launches"], 1), 4) for k, x in idxs[v].stats().items() if x["launches"]}
         print(f"variant {v:>5}: step ms min {dts[0]:.3f} med {dts[len(dts)//2]:.3f} | k_fill ms min {fl[0]:.3f} med {fl[len(fl)//2]:.3f} "
               f"-> {8 * hits / fl[0] / 1e6:.0f} GB/s algorithmic ({8 * hits / fl[0] / 1e6 / 8000 * 100:.1f}% of 8 TB/s)", flush=True)
     assert len(set(digest.values())) == 1
