@@ -27,10 +27,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=100_000_000, help="text length")
-    ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--sigma", type=int, default=4)
-    ap.add_argument("--nq", type=int, default=10_000_000, help="queries per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[N-1]; 2 = the metric's workload (default), 3/4/5 are informational")
+    ap.add_argument("--n", type=int, default=0, help="text length (0 = the config's)")
+    ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (0 = the config's)")
     ap.add_argument("--table", choices=["open", "dense", "auto"], default="open")
     ap.add_argument("--gather", choices=["totals", "hits"], default="totals",
                     help="totals: hit lists stay sharded where they were produced, per-shard totals exchanged after the timed region "
@@ -69,25 +69,39 @@ def main():
         if rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
+    # (sigma, n, ks, queries per GPU, query lengths, planted share, text seed, query seed)
+    CFG = {2: (4, 100_000_000, [10], 10_000_000, [10], 0.0, 1002, 2002),
+           3: (4, 100_000_000, [8, 10, 12], 10_000_000, [8, 10, 12, 20, 22, 24], 0.5, 1003, 2003),
+           4: (5, 100_000_000, [10], 12_500_000, [10], 0.0, 1004, 2004),
+           5: (20, 10_000_000, [5], 10_000_000, [5], 0.5, 1005, 2005)}
+    sigma, n_cfg, ks, nq_cfg, qlens, planted, tseed, qseed = CFG[args.config]
+    args.sigma, args.k = sigma, ks[0] if len(ks) == 1 else 0
+    args.n = args.n or n_cfg
+    args.nq = args.nq or nq_cfg
     t0 = time.time()
-    text = synth.ranks(1002, args.n, args.sigma)                      # identical on every rank
+    text = synth.ranks(tseed, args.n, args.sigma)                     # identical on every rank
     log(f"text n={args.n} sigma={args.sigma} generated in {time.time() - t0:.1f}s")
     t0 = time.time()
     table = {"open": engine.TABLE_OPEN, "dense": engine.TABLE_DENSE, "auto": engine.TABLE_AUTO}[args.table]
-    idx = engine.Index(text, args.sigma, [args.k], table=table, device=dev_index)
+    idx = engine.Index(text, args.sigma, ks, table=table, device=dev_index)
     info = idx.info()
     log(f"index built+uploaded in {time.time() - t0:.1f}s: {info}")
 
     # this rank's query shard: letters [rank*nq*m, (rank+1)*nq*m) of query stream 2002
-    m = args.k
     nq = args.nq
-    qr_host = np.empty(nq * m, np.uint8)
-    chunk = 1 << 24
-    for s in range(0, nq * m, chunk):
-        e = min(nq * m, s + chunk)
-        z = synth.u64_stream(2002, e - s, rank * nq * m + s)
-        qr_host[s:e] = (((z >> np.uint64(32)) * np.uint64(args.sigma)) >> np.uint64(32)).astype(np.uint8)
-    qoff_host = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+    if planted == 0.0:
+        m = qlens[0]
+        qr_host = np.empty(nq * m, np.uint8)
+        chunk = 1 << 24
+        for s in range(0, nq * m, chunk):
+            e = min(nq * m, s + chunk)
+            z = synth.u64_stream(qseed, e - s, rank * nq * m + s)
+            qr_host[s:e] = (((z >> np.uint64(32)) * np.uint64(args.sigma)) >> np.uint64(32)).astype(np.uint8)
+        qoff_host = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+    else:
+        m = 0
+        qr_host, qoff_host = synth.mixed_queries(qseed + 7919 * rank, text, nq, qlens, args.sigma, planted_frac=planted)
+    n_letters = int(qoff_host[-1])
     d_qr = torch.from_numpy(qr_host).to(dev)
     d_qoff = torch.from_numpy(qoff_host.view(np.int64)).to(dev)
     torch.cuda.synchronize()
@@ -135,11 +149,11 @@ def main():
         from oracle import orc
         nv = min(args.verify, nq)
         hit_off, positions, status, kinds = res.host()
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.config == 2:
             t1 = time.time()
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
             T = args.cpu_threads or max(1, min(16, usable))
-            oidx = orc.Index(text, args.sigma, [args.k], n_threads=T)
+            oidx = orc.Index(text, args.sigma, ks, n_threads=T)
             log(f"oracle (CPU restatement) index built in {time.time() - t1:.1f}s")
             ns = min(args.cpu_sample, nq)
             t1 = time.perf_counter()
@@ -152,10 +166,16 @@ def main():
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
             oidx.close()
         else:
-            # no oracle index at this size: ground-truth a few queries by naive scan of the text prefix property
-            qi = np.repeat(np.arange(nv), np.diff(hit_off[:nv + 1]).astype(np.int64))
+            # no oracle index in this leg: every reported position of the first queries must re-read to its query
+            nv = min(nv, 2000)
+            cntv = np.diff(hit_off[:nv + 1]).astype(np.int64)
+            qi = np.repeat(np.arange(nv), cntv)
             pos = positions[:int(hit_off[nv])].astype(np.int64)
-            ok = all(np.array_equal(text[pos + j], qr_host.reshape(-1, m)[qi, j]) for j in range(m))
+            lens = np.diff(qoff_host[:nv + 1]).astype(np.int64)
+            ok = True
+            for j in range(int(lens.max()) if nv else 0):
+                sel = lens[qi] > j
+                ok &= bool(np.array_equal(text[pos[sel] + j], qr_host[qoff_host[qi[sel]].astype(np.int64) + j]))
             verified = bool(ok)
         if not verified:
             log("VERIFICATION FAILED")
@@ -169,7 +189,7 @@ def main():
         n_hits_rank = counts["n_hits"]
         # algorithmic bytes: per query R = m + 16 + 4c, W = 8 + 4c.  k_fill moves the 4c + 4c part.
         fill_bytes = 8.0 * n_hits_rank
-        job_bytes = float(nq) * (m + 16 + 8) + 8.0 * n_hits_rank
+        job_bytes = float(n_letters) + float(nq) * (16 + 8) + 8.0 * n_hits_rank
         achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
         kernels_ms = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items() if v["launches"]}
         # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 --pmc
@@ -182,7 +202,7 @@ def main():
         except Exception:
             pass
         out = {
-            "metric": "M queries/sec, DNA4 k=10 exact-match batch search, 1e8-bp text",
+            "metric": "M queries/sec, DNA4 k=10 exact-match batch search, 1e8-bp text" if args.config == 2 else f"M queries/sec, BASELINE configs[{args.config - 1}] (informational)",
             "value": round(value, 3),
             "unit": "M queries/s",
             "n_gpus": world,
@@ -194,8 +214,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32/u64",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: DNA4 text {args.n} bp, k={args.k}, {nq} uniform random {m}-mer queries per GPU per step, "
-                                   f"materialised sorted position lists (to_vector), table={args.table}",
+            "config": {"workload": f"BASELINE configs[{args.config - 1}]: sigma={args.sigma} text {args.n} letters, ks={ks}, {nq} queries per GPU per step "
+                                   f"(lengths {qlens}, planted share {planted}), materialised sorted position lists (to_vector), table={args.table}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
                        "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated", "gather": args.gather},
             "roofline": {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

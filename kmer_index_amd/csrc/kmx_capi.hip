@@ -148,7 +148,7 @@ struct kmx_result {
     uint64_t nq = 0, n_hits = 0, n_exact = 0, n_stitch = 0, n_prefix = 0, n_error = 0, n_none = 0;
     uint64_t n_mask_words = 0;
     // device
-    DevBuf src, cnt, c0, aux, key, kind, status, stitch_list, prefix_list, hit_off, bsum, ctr, tile_q, out,
+    DevBuf src, cnt, c0, aux, key, p1, kind, status, stitch_list, prefix_list, hit_off, bsum, ctr, tile_q, out,
         mask_words, plen, poff, ptmp, in_qranks, in_qoff;
     unsigned long long* h_ctr = nullptr;   // pinned
     // host mirrors
@@ -157,7 +157,7 @@ struct kmx_result {
 
     void release()
     {
-        for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
+        for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
                           &tile_q, &out, &mask_words, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
             b->release();
         for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src})
@@ -501,6 +501,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->c0.ensure(nq * 4));
     HIP_TRY(r->aux.ensure(nq * 8));
     HIP_TRY(r->key.ensure(nq * 8));
+    HIP_TRY(r->p1.ensure(nq * 8));
     HIP_TRY(r->kind.ensure(nq));
     HIP_TRY(r->status.ensure(nq));
     HIP_TRY(r->stitch_list.ensure(nq * 4));
@@ -508,7 +509,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->bsum.ensure(kmx::scan_blocks(nq) * 8));
     HIP_TRY(r->ctr.ensure(KMX_CTR_COUNT * sizeof(unsigned long long)));
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
-                     r->key.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
+                     r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
                      r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>()};
     auto* ctr = r->ctr.as<unsigned long long>();
     const KmxIndexDev* dix = ix->d_index;

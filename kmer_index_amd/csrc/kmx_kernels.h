@@ -13,7 +13,8 @@ struct QueryDesc {
     uint32_t* cnt;          // number of hits (STITCH: written by k_validate)
     uint32_t* c0;           // STITCH: number of candidates; PREFIX: number of runs in the slice
     uint64_t* aux;          // STITCH: index of the first mask word; PREFIX: last-kmer bits (bit j <-> position n-j)
-    uint64_t* key;          // PREFIX: key index of the first run (offs + key bounds the runs)
+    uint64_t* key;          // PREFIX: key index of the first run (offs + key bounds the runs); STITCH: arena index of the single further part's bucket
+    uint64_t* p1;           // STITCH: (offset of the single further part in the query << 32) | its bucket size, ~0 when there are several
     uint8_t* kind;          // kmx_query_kind
     uint8_t* status;        // kmx_query_status
     uint32_t* stitch_list;  // indices of the STITCH queries (arbitrary order)

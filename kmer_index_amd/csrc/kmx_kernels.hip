@@ -24,6 +24,7 @@
 
 #define KMX_BLOCK 256
 #define KMX_WAVE 64
+#define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
 
 namespace kmx {
 
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     const uint64_t q = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
     uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
     uint64_t src = 0, aux = 0, key = 0;
+    uint64_t p1 = ~uint64_t(0);   // STITCH with exactly one further part: (offset in query << 32) | bucket size, bucket in `key`
     uint32_t cnt = 0, c0 = 0;
     unsigned int my_stitch = 0, my_prefix = 0;
     unsigned long long my_words = 0;
@@ -225,13 +227,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                 } else {                                      // m > k, :207-339
                     const uint32_t P = uint32_t(m / k), rest = uint32_t(m % k);
                     bool all = true;
-                    Run first{0, 0};
+                    Run first{0, 0}, extra{0, 0};
+                    uint32_t extra_delta = 0;
                     for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
                         uint64_t h;
                         ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h);
                         if (!ranks_ok) break;
                         Run r = probe(el, h);
-                        if (j == 0) first = r;
+                        if (j == 0) first = r; else { extra = r; extra_delta = j * k; }
                         all = r.cnt != 0;
                     }
                     if (all && ranks_ok) {
@@ -242,10 +245,12 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                                 // the rest is verified through the k-mer that ENDS the query
                                 uint64_t h;
                                 ranks_ok = rank_hash(qr + (m - k), k, sigma, h);
-                                all = ranks_ok && probe(el, h).cnt != 0;
+                                if (ranks_ok) { extra = probe(el, h); extra_delta = uint32_t(m - k); }
+                                all = ranks_ok && extra.cnt != 0;
                             }
                             if (all && ranks_ok) {
                                 kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
+                                if (P - 1 + (rest ? 1 : 0) == 1) { key = extra.src; p1 = (uint64_t(extra_delta) << 32) | extra.cnt; }
                             }
                         }
                     }
@@ -254,7 +259,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                 // walk _optimal_nk_sum[m] from its last summand to its first
                 uint64_t mm = m;
                 bool all = true;
-                Run r{0, 0};
+                Run r{0, 0}, extra{0, 0};
+                uint32_t extra_delta = 0;
                 const uint32_t nparts = pe.nparts;
                 for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
                     const KmxPlanEntry e = load_plan(ix, mm);
@@ -265,11 +271,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                     ranks_ok = rank_hash(qr + mm, k, sigma, h);
                     if (!ranks_ok) break;
                     r = probe(el, h);                         // search_k, :183-190 / :520
+                    if (j == 0) { extra = r; extra_delta = uint32_t(mm); }
                     all = r.cnt != 0;                         // :521-524
                 }
                 if (all && ranks_ok) {
                     if (nparts == 1) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }   // :529-530
-                    else { kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt; }
+                    else {
+                        kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
+                        if (nparts == 2) { key = extra.src; p1 = (uint64_t(extra_delta) << 32) | extra.cnt; }
+                    }
                 }
             }
             if (!ranks_ok) { status = KMX_Q_BAD_RANK; kind = KMX_KIND_NONE; cnt = 0; my_prefix = 0; }
@@ -319,6 +329,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         if (kind == KMX_KIND_STITCH) {
             d.c0[q] = c0;
             d.aux[q] = bc.base_words + loc_words;             // first mask word of this query
+            d.key[q] = key;
+            d.p1[q] = p1;
             d.stitch_list[bc.base_stitch + loc_stitch] = uint32_t(q);
         } else if (kind == KMX_KIND_PREFIX) {
             d.c0[q] = c0;
@@ -346,20 +358,59 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                                                         const uint64_t* __restrict__ qoff, QueryDesc d,
                                                         uint64_t n_stitch, uint64_t* __restrict__ mask_words)
 {
+    // part bucket staged per wave (the common 2-part stitch): binary searches then run at LDS latency
+    __shared__ uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_STAGE_CAP];
     const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x / KMX_WAVE;
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
     const uint32_t sigma = ix->sigma;
 
     for (uint64_t i = wave; i < n_stitch; i += n_waves) {
         const uint32_t q = d.stitch_list[i];
+        // everything the fast path needs is one round of independent loads
+        const uint32_t c0 = d.c0[q];
+        const uint64_t src = d.src[q] & ~SRC_SLOW;
+        const uint64_t p1 = d.p1[q];
+        const uint64_t p1src = d.key[q];
+        uint64_t* __restrict__ words = mask_words + d.aux[q];
+        const uint32_t n_words = c0 / 64 + 1;                          // compressed_bitset.hpp:23
+        if (p1 != ~uint64_t(0)) {
+            const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32);
+            const bool staged = pcnt <= KMX_STAGE_CAP;
+            if (staged) {
+                for (uint32_t t = lane; t < pcnt; t += KMX_WAVE) stage[wv][t] = arena[p1src + t];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            uint32_t valid = 0;
+            for (uint32_t w = 0; w < n_words; ++w) {
+                const uint32_t ci = w * 64 + lane;
+                bool ok = ci < c0;
+                const uint32_t x = (ok ? arena[src + ci] : 0u) + delta;
+                if (staged) {
+                    uint32_t lo = 0, hi = pcnt;                         // lower_bound in LDS
+                    while (lo < hi) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if (stage[wv][mid] < x) lo = mid + 1; else hi = mid;
+                    }
+                    ok = ok && lo < pcnt && stage[wv][lo] == x;         // binary_search :283, lower_bound :544-546
+                } else if (ok) {
+                    const uint64_t pos = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x);
+                    ok = pos < pcnt && arena[p1src + pos] == x;
+                }
+                const uint64_t word = __ballot(ok);                    // 64 candidates = one bitset word
+                if (lane == 0) words[w] = word;
+                valid += uint32_t(__popcll(word));
+            }
+            if (lane == 0) d.cnt[q] = valid;
+            __builtin_amdgcn_wave_barrier();                           // stage[] is reused by the next query
+            continue;
+        }
         const uint64_t b = qoff[q];
         const uint64_t m = qoff[q + 1] - b;
         const uint8_t* __restrict__ qr = qranks + b;
-        const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q] & ~SRC_SLOW;
-        uint64_t* __restrict__ words = mask_words + d.aux[q];
-        const uint32_t n_words = c0 / 64 + 1;                          // compressed_bitset.hpp:23
         const KmxPlanEntry pe = load_plan(ix, m);
 
         // parts beyond the first one
