@@ -517,9 +517,21 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(hipMemsetAsync(ctr, 0, KMX_CTR_COUNT * sizeof(unsigned long long), s));
     timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr); });
     // speculative scan: already final when the batch holds no STITCH query
-    timed(ix, K_SCAN, s, [&] {
-        kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
-    });
+    // The downsweep also records the first query of every output tile (k_partition's job) when the
+    // tile table kept from an earlier batch is large enough — the steady state.
+    const kmx::FillVariant fv = ix->fill_variant;
+    const uint64_t tile = kmx::fill_tile(fv);
+    const uint64_t tile_cap = r->tile_q.cap / 4;            // entries available while the scan runs
+    auto scan_hits = [&] {
+        timed(ix, K_SCAN, s, [&] {
+            if (tile_cap >= 2)
+                kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS,
+                                       tile, tile_cap - 1, r->tile_q.as<uint32_t>());
+            else
+                kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
+        });
+    };
+    scan_hits();
     HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     r->n_stitch = r->h_ctr[KMX_CTR_STITCH];
@@ -534,9 +546,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     if (r->n_stitch) {
         HIP_TRY(r->mask_words.ensure(r->n_mask_words * 8));
         timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, r->n_stitch, r->mask_words.as<uint64_t>()); });
-        timed(ix, K_SCAN, s, [&] {
-            kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
-        });
+        scan_hits();
         HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
     }
@@ -545,15 +555,14 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
 
     const uint64_t total = r->n_hits;
     if (total == 0) return KMX_OK;
-    const kmx::FillVariant fv = ix->fill_variant;
-    const uint64_t tile = kmx::fill_tile(fv);
     const uint64_t n_tiles = (total + tile - 1) / tile;
     if (n_tiles >= 0x7FFFFFFFull) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: result too large, split the batch");
     HIP_TRY(r->out.ensure(total * 4));
     HIP_TRY(r->tile_q.ensure((n_tiles + 1) * 4));
     uint32_t* out = r->out.as<uint32_t>();
     const uint64_t* hit_off = r->hit_off.as<uint64_t>();
-    timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, tile, n_tiles, r->tile_q.as<uint32_t>()); });
+    if (n_tiles + 1 > tile_cap)   // first batch / the table had to grow: the scan could not fill it
+        timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, tile, n_tiles, r->tile_q.as<uint32_t>()); });
     timed(ix, K_FILL, s, [&] { kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, hit_off, r->tile_q.as<uint32_t>(), total, n_tiles, d, out); });
     if (r->n_stitch)
         timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });

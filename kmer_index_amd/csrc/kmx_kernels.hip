@@ -554,9 +554,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_spine(uint64_t* __restrict__
     if (threadIdx.x == 0) *total_out = running;
 }
 
+// Downsweep.  With TILES it also does the work of k_partition for the offsets it produces: query i
+// owns output slots [ex, ex + v); every tile boundary t*tile inside that range gets tile_q[t] = i
+// (the last query whose offset is <= the boundary), and tile_q[t] for boundaries at or past the
+// total is n - 1.
+template <bool TILES>
 __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restrict__ in, uint64_t n,
                                                          const uint64_t* __restrict__ bsum,
-                                                         uint64_t* __restrict__ out)
+                                                         uint64_t* __restrict__ out, uint64_t tile,
+                                                         uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q)
 {
     // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS) of the tile
     const uint64_t base = uint64_t(blockIdx.x) * KMX_SCAN_TILE + uint64_t(threadIdx.x) * KMX_SCAN_ITEMS;
@@ -573,8 +579,22 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
     for (int j = 0; j < KMX_SCAN_ITEMS; ++j) {
         uint64_t i = base + j;
         if (i < n) out[i] = ex;
+        if constexpr (TILES) {
+            if (i < n && v[j]) {
+                // boundaries x = t*tile with ex <= x < ex + v[j]
+                uint64_t t = (ex + tile - 1) / tile;
+                const uint64_t t_end = (ex + v[j] - 1) / tile;
+                for (; t <= t_end && t <= n_tiles_cap; ++t) tile_q[t] = uint32_t(i);
+            }
+        }
         ex += v[j];
-        if (i + 1 == n) out[n] = ex;
+        if (i + 1 == n) {
+            out[n] = ex;
+            if constexpr (TILES) {
+                // boundaries at or beyond the total: the last query
+                for (uint64_t t = (ex + tile - 1) / tile; t <= n_tiles_cap && t <= (ex + tile - 1) / tile + 1; ++t) tile_q[t] = uint32_t(n - 1);
+            }
+        }
     }
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
 }
@@ -906,7 +926,17 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, 
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL(k_scan_down, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out);
+    hipLaunchKernelGGL(k_scan_down<false>, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0), (uint32_t*)nullptr);
+}
+
+// scan + first-query-of-every-tile in one downsweep; tile_q must hold n_tiles_cap + 1 entries
+void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q)
+{
+    const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
+    hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
+    hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
+    hipLaunchKernelGGL(k_scan_down<true>, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q);
 }
 
 // fill variants, selected at run time (KMX_FILL_VARIANT, see kmx_capi.hip)

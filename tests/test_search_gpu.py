@@ -139,3 +139,38 @@ def test_masks_match_oracle_bitset(engine, orc):
         assert np.array_equal(cands[bits], pos[int(ho[i]):int(ho[i + 1])])
         n_checked += 1
     assert n_checked > 10
+
+
+def test_result_reuse_and_growth(engine, orc):
+    """One result handle reused across batches of growing and shrinking size (exercises the fused
+    scan+tile-table path, the fallback partition kernel, and buffer growth)."""
+    text = synth.ranks(77, 300_000, 4)
+    idx = engine.Index(text, 4, [7])
+    oidx = orc.Index(text, 4, [7])
+    res = engine.Result()
+    for nq in (10, 5000, 300, 40000, 40000, 1, 20000):
+        qranks, qoff = synth.uniform_queries(500 + nq, nq, 7, 4)
+        idx.search(qranks, qoff, result=res)
+        ho, pos, st, kd = res.host()
+        o_off, o_pos, _, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+        assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), nq
+
+
+def test_skewed_text_giant_buckets(engine, orc):
+    """Low-entropy text: a few giant buckets (load imbalance, runs far longer than a tile, many mask words)."""
+    n = 120_000
+    text = np.zeros(n, np.uint8)
+    text[::997] = 1
+    text[5::4001] = 2
+    idx = engine.Index(text, 4, [5, 9])
+    oidx = orc.Index(text, 4, [5, 9])
+    qs = [np.zeros(m, np.uint8) for m in (2, 5, 7, 9, 10, 14, 18, 23)]
+    qs += [text[990:990 + m].copy() for m in (5, 9, 12, 18)] + [text[n - m:].copy() for m in (3, 5, 9, 14)]
+    qranks, qoff = pack(qs)
+    r = idx.search(qranks, qoff)
+    ho, pos, st, kd = r.host()
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+    assert np.array_equal(st, o_st.astype(np.uint8))
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    for i, q in enumerate(qs):
+        assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, q))
