@@ -24,6 +24,7 @@
 
 #define KMX_BLOCK 256
 #define KMX_WAVE 64
+#define KMX_LOOKUP_ITEMS 4     // queries per thread in k_lookup
 #define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
 
 namespace kmx {
@@ -156,7 +157,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     }
     __syncthreads();
 
-    const uint64_t q = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    // a block serves KMX_LOOKUP_ITEMS * 256 queries so that the (returning) global atomics of the
+    // work-list bookkeeping are paid once per 1024 queries
+    uint8_t kinds[KMX_LOOKUP_ITEMS];
+    unsigned int locs[KMX_LOOKUP_ITEMS];
+    unsigned long long locw[KMX_LOOKUP_ITEMS];
+#pragma unroll 1
+    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+    const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
     uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
     uint64_t src = 0, aux = 0, key = 0;
     uint64_t p1 = ~uint64_t(0);   // STITCH with exactly one further part: (offset in query << 32) | bucket size, bucket in `key`
@@ -290,21 +298,40 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         }
     }
 
-    // block-aggregated bookkeeping (one global atomic per counter per block, none for
-    // a block of plain exact hits)
-    unsigned int loc_stitch = 0, loc_prefix = 0;
+    // block-aggregated bookkeeping: LDS counters now, one global atomic per counter per block later
+    unsigned int loc = 0;
     unsigned long long loc_words = 0;
     if (my_stitch) {
-        loc_stitch = atomicAdd(&bc.n_stitch, 1u);
+        loc = atomicAdd(&bc.n_stitch, 1u);
         loc_words = atomicAdd(&bc.words, my_words);
     }
     if (my_prefix) {
-        loc_prefix = atomicAdd(&bc.n_prefix, 1u);
+        loc = atomicAdd(&bc.n_prefix, 1u);
         atomicAdd(&bc.pelems, (unsigned long long)(cnt - __popcll(aux)));
         atomicMax(&bc.max_runs, c0);
     }
     if (q < nq && status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
     if (q < nq && status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
+    kinds[it] = q < nq ? kind : uint8_t(KMX_KIND_NONE);
+    locs[it] = loc;
+    locw[it] = loc_words;
+    if (q < nq) {
+        d.src[q] = (kind == KMX_KIND_STITCH || kind == KMX_KIND_PREFIX) ? (src | SRC_SLOW) : src;
+        d.cnt[q] = cnt;
+        d.kind[q] = kind;
+        d.status[q] = status;
+        if (kind == KMX_KIND_STITCH) {
+            d.c0[q] = c0;
+            d.key[q] = key;
+            d.p1[q] = p1;
+        } else if (kind == KMX_KIND_PREFIX) {
+            d.c0[q] = c0;
+            d.aux[q] = aux;
+            d.key[q] = key;
+        }
+    }
+    }   // items
+
     __syncthreads();
     if (threadIdx.x == 0) {
         if (bc.n_stitch) {
@@ -320,23 +347,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         if (bc.n_none) atomicAdd(&ctr[KMX_CTR_NONE], (unsigned long long)bc.n_none);
     }
     __syncthreads();
-
-    if (q < nq) {
-        d.src[q] = (kind == KMX_KIND_STITCH || kind == KMX_KIND_PREFIX) ? (src | SRC_SLOW) : src;
-        d.cnt[q] = cnt;
-        d.kind[q] = kind;
-        d.status[q] = status;
-        if (kind == KMX_KIND_STITCH) {
-            d.c0[q] = c0;
-            d.aux[q] = bc.base_words + loc_words;             // first mask word of this query
-            d.key[q] = key;
-            d.p1[q] = p1;
-            d.stitch_list[bc.base_stitch + loc_stitch] = uint32_t(q);
-        } else if (kind == KMX_KIND_PREFIX) {
-            d.c0[q] = c0;
-            d.aux[q] = aux;
-            d.key[q] = key;
-            d.prefix_list[bc.base_prefix + loc_prefix] = uint32_t(q);
+#pragma unroll
+    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+        const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+        if (kinds[it] == KMX_KIND_STITCH) {
+            d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
+            d.stitch_list[bc.base_stitch + locs[it]] = uint32_t(q);
+        } else if (kinds[it] == KMX_KIND_PREFIX) {
+            d.prefix_list[bc.base_prefix + locs[it]] = uint32_t(q);
         }
     }
 }
@@ -907,7 +925,7 @@ static inline unsigned int blocks_for(uint64_t n, uint64_t per_block)
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr)
 {
-    hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
+    hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
 }
 
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
