@@ -49,6 +49,12 @@ def lib():
     """Loads kmer_index_amd/libkmx.so, building it first when stale (hipcc, gfx950)."""
     global _lib
     if _lib is None:
+        # One HIP runtime per process: torch ships its own libamdhip64.so.7 and finds no GPU when another copy
+        # (the /opt/rocm one libkmx.so links to) was mapped first.  Importing torch first makes both share torch's.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         path = _build.build()
         if not os.path.exists(path):
             raise RuntimeError("libkmx.so is missing and could not be built; the engine has no fallback")

@@ -174,3 +174,57 @@ def test_skewed_text_giant_buckets(engine, orc):
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
     for i, q in enumerate(qs):
         assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, q))
+
+
+def test_concurrent_host_threads_share_one_index(engine, orc):
+    """kmx.h: one index may be searched from several host threads at once (search() is const in the reference,
+    kmer_index.hpp:505).  Host-buffer calls serialise on the index's internal stream; device-buffer calls run on
+    their own streams with their own result handles."""
+    import threading
+    import torch
+    text = synth.ranks(31337, 400_000, 4)
+    idx = engine.Index(text, 4, [8, 11])
+    oidx = orc.Index(text, 4, [8, 11])
+    batches = []
+    for t in range(6):
+        q, off = make_queries(text, 4, [5, 8, 11, 16, 19, 22], 40, seed=100 + t)
+        o = oidx.search_batch(q, off, n_threads=2)
+        batches.append((q, off, o[0], o[1]))
+    errors = []
+
+    def host_worker(t):
+        try:
+            q, off, want_off, want_pos = batches[t]
+            for _ in range(5):
+                ho, pos, st, kd = idx.search(q, off).host()
+                assert np.array_equal(ho, want_off) and np.array_equal(pos, want_pos)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    # torch objects are created on the main thread (torch's lazy CUDA init is not re-entrant across threads)
+    dev = torch.device("cuda", 0)
+    torch.cuda.init()
+    dev_inputs = {}
+    for t in range(1, 6, 2):
+        q, off, _, _ = batches[t]
+        dev_inputs[t] = (torch.cuda.Stream(device=dev), torch.from_numpy(q).to(dev), torch.from_numpy(off.view(np.int64)).to(dev))
+    torch.cuda.synchronize()
+
+    def device_worker(t):
+        try:
+            q, off, want_off, want_pos = batches[t]
+            stream, d_q, d_off = dev_inputs[t]
+            res = engine.Result()
+            for _ in range(5):
+                idx.search_device(d_q.data_ptr(), d_off.data_ptr(), off.size - 1, stream=stream.cuda_stream, result=res)
+                ho, pos, st, kd = res.host()
+                assert np.array_equal(ho, want_off) and np.array_equal(pos, want_pos)
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=host_worker if t % 2 == 0 else device_worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
