@@ -370,147 +370,187 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 // both decide "the text continues with the rest of the query at p + P*k".
 // 64 candidates = one compressed_bitset word, produced by one ballot.
 // ---------------------------------------------------------------------------
+// General STITCH query (any number of parts), one wave per query.
+__device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
+                                      const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff,
+                                      const QueryDesc& d, uint32_t q, uint64_t* __restrict__ mask_words)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t sigma = ix->sigma;
+    const uint32_t c0 = d.c0[q];
+    const uint64_t src = d.src[q] & ~SRC_SLOW;
+    uint64_t* __restrict__ words = mask_words + d.aux[q];
+    const uint32_t n_words = c0 / 64 + 1;                              // compressed_bitset.hpp:23
+    const uint64_t b = qoff[q];
+    const uint64_t m = qoff[q + 1] - b;
+    const uint8_t* __restrict__ qr = qranks + b;
+    const KmxPlanEntry pe = load_plan(ix, m);
+
+    // parts beyond the first one
+    uint32_t n_extra, sk = 0, sP = 0;
+    const KmxElemDev* __restrict__ sel = nullptr;
+    if (pe.scheme == KMX_SCHEME_SINGLE) {
+        sel = &ix->elems[pe.elem];
+        sk = sel->k;
+        sP = uint32_t(m / sk);
+        n_extra = sP - 1 + ((m % sk) ? 1 : 0);
+    } else {
+        n_extra = pe.nparts - 1u;
+    }
+
+    // lane = part: (bucket, offset of the part inside the query)
+    uint64_t p_src = 0;
+    uint32_t p_cnt = 0, p_delta = 0;
+    uint64_t mm = m;   // multi scheme: cursor of the walk over _optimal_nk_sum[m], last summand first
+    auto load_parts = [&](uint32_t base_part, uint32_t chunk) {
+        if (pe.scheme == KMX_SCHEME_SINGLE) {
+            if (lane < chunk) {
+                const uint32_t part = base_part + lane;
+                // j = 1 .. P-1 at j*k (:279-291), then, for a rest, the k-mer that ends the query
+                const uint64_t start = (part < sP - 1) ? uint64_t(part + 1) * sk : (m - sk);
+                uint64_t h;
+                rank_hash(qr + start, sk, sigma, h);
+                const Run r = probe(sel, h);
+                p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(start);
+            }
+        } else {
+            // the walk is serial and wave-uniform; lane s keeps step s
+            for (uint32_t s = 0; s < chunk; ++s) {
+                const KmxPlanEntry e = load_plan(ix, mm);
+                const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
+                const uint32_t k = el->k;
+                mm -= k;                                           // this summand covers [mm, mm + k)
+                if (lane == s) {
+                    uint64_t h;
+                    rank_hash(qr + mm, k, sigma, h);
+                    const Run r = probe(el, h);                    // search_k, :520
+                    p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(mm);
+                }
+            }
+        }
+    };
+    auto check_parts = [&](uint32_t chunk, uint32_t p, bool ok) -> bool {
+        for (uint32_t s = 0; s < chunk; ++s) {
+            const uint64_t bs = __shfl(p_src, int(s));
+            const uint32_t bn = __shfl(p_cnt, int(s));
+            const uint32_t dl = __shfl(p_delta, int(s));
+            if (ok) {
+                const uint32_t x = p + dl;
+                const uint64_t pos = lower_bound_dev<uint32_t>(arena + bs, bn, x);
+                ok = pos < bn && arena[bs + pos] == x;             // binary_search :283, lower_bound :544-546
+            }
+            if (!__any(ok)) break;
+        }
+        return ok;
+    };
+
+    const bool one_chunk = n_extra <= KMX_WAVE;
+    if (one_chunk) load_parts(0, n_extra);
+    uint32_t valid = 0;
+    for (uint32_t w = 0; w < n_words; ++w) {
+        const uint32_t ci = w * 64 + lane;
+        bool ok = ci < c0;
+        const uint32_t p = ok ? arena[src + ci] : 0;
+        if (one_chunk) {
+            ok = check_parts(n_extra, p, ok);
+        } else {
+            mm = m;
+            for (uint32_t base_part = 0; base_part < n_extra && __any(ok); base_part += KMX_WAVE) {
+                const uint32_t chunk = min(uint32_t(KMX_WAVE), n_extra - base_part);
+                load_parts(base_part, chunk);
+                ok = check_parts(chunk, p, ok);
+            }
+        }
+        const uint64_t word = __ballot(ok);                        // 64 candidates = one bitset word
+        if (lane == 0) words[w] = word;
+        valid += uint32_t(__popcll(word));
+    }
+    if (lane == 0) d.cnt[q] = valid;
+}
+
+// Fast path: STITCH queries with exactly one further part (2 multi-k summands, 2 k-parts, or one
+// k-part + rest) — KMX_VGROUPS queries per wave, one per KMX_VGROUP-lane group, the part's bucket
+// staged in LDS so that the per-candidate binary search runs at LDS latency.  64 candidates = one
+// compressed_bitset word, assembled from KMX_VGROUP-bit slices of the wave's ballots.
+#ifndef KMX_VGROUP
+#define KMX_VGROUP 16
+#endif
+#define KMX_VGROUPS (KMX_WAVE / KMX_VGROUP)
+#define KMX_VSLICES (64 / KMX_VGROUP)            // ballot slices per mask word
+#define KMX_VSTAGE (1024 / KMX_VGROUPS)          // staged bucket entries per group (4 KB of LDS per wave)
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
                                                         const uint32_t* __restrict__ arena,
                                                         const uint8_t* __restrict__ qranks,
                                                         const uint64_t* __restrict__ qoff, QueryDesc d,
                                                         uint64_t n_stitch, uint64_t* __restrict__ mask_words)
 {
-    // part bucket staged per wave (the common 2-part stitch): binary searches then run at LDS latency
-    __shared__ uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_STAGE_CAP];
+    __shared__ uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VSTAGE];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x / KMX_WAVE;
+    const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
+    const uint64_t slice_mask = (KMX_VGROUP == 64) ? ~uint64_t(0) : ((uint64_t(1) << (KMX_VGROUP & 63)) - 1);
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
-    const uint32_t sigma = ix->sigma;
 
-    for (uint64_t i = wave; i < n_stitch; i += n_waves) {
-        const uint32_t q = d.stitch_list[i];
-        // everything the fast path needs is one round of independent loads
-        const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q] & ~SRC_SLOW;
-        const uint64_t p1 = d.p1[q];
-        const uint64_t p1src = d.key[q];
-        uint64_t* __restrict__ words = mask_words + d.aux[q];
-        const uint32_t n_words = c0 / 64 + 1;                          // compressed_bitset.hpp:23
-        if (p1 != ~uint64_t(0)) {
-            const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32);
-            const bool staged = pcnt <= KMX_STAGE_CAP;
-            if (staged) {
-                for (uint32_t t = lane; t < pcnt; t += KMX_WAVE) stage[wv][t] = arena[p1src + t];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
-            uint32_t valid = 0;
-            for (uint32_t w = 0; w < n_words; ++w) {
-                const uint32_t ci = w * 64 + lane;
-                bool ok = ci < c0;
-                const uint32_t x = (ok ? arena[src + ci] : 0u) + delta;
-                if (staged) {
-                    uint32_t lo = 0, hi = pcnt;                         // lower_bound in LDS
-                    while (lo < hi) {
-                        const uint32_t mid = (lo + hi) >> 1;
-                        if (stage[wv][mid] < x) lo = mid + 1; else hi = mid;
-                    }
-                    ok = ok && lo < pcnt && stage[wv][lo] == x;         // binary_search :283, lower_bound :544-546
-                } else if (ok) {
-                    const uint64_t pos = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x);
-                    ok = pos < pcnt && arena[p1src + pos] == x;
-                }
-                const uint64_t word = __ballot(ok);                    // 64 candidates = one bitset word
-                if (lane == 0) words[w] = word;
-                valid += uint32_t(__popcll(word));
-            }
-            if (lane == 0) d.cnt[q] = valid;
-            __builtin_amdgcn_wave_barrier();                           // stage[] is reused by the next query
-            continue;
-        }
-        const uint64_t b = qoff[q];
-        const uint64_t m = qoff[q + 1] - b;
-        const uint8_t* __restrict__ qr = qranks + b;
-        const KmxPlanEntry pe = load_plan(ix, m);
+    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
+        const uint64_t i = i0 + g;
+        const bool have = i < n_stitch;
+        const uint32_t q = have ? d.stitch_list[i] : 0u;
+        // one round of independent loads per group
+        const uint32_t c0 = have ? d.c0[q] : 0u;
+        const uint64_t src = have ? (d.src[q] & ~SRC_SLOW) : 0;
+        const uint64_t p1 = have ? d.p1[q] : ~uint64_t(0);
+        const uint64_t p1src = have ? d.key[q] : 0;
+        uint64_t* __restrict__ words = mask_words + (have ? d.aux[q] : 0);
+        const bool fast = have && p1 != ~uint64_t(0);
+        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32);
+        const bool staged = fast && pcnt <= KMX_VSTAGE;
+        if (staged)
+            for (uint32_t t = gl; t < pcnt; t += KMX_VGROUP) stage[wv][g][t] = arena[p1src + t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        // parts beyond the first one
-        uint32_t n_extra, sk = 0, sP = 0;
-        const KmxElemDev* __restrict__ sel = nullptr;
-        if (pe.scheme == KMX_SCHEME_SINGLE) {
-            sel = &ix->elems[pe.elem];
-            sk = sel->k;
-            sP = uint32_t(m / sk);
-            n_extra = sP - 1 + ((m % sk) ? 1 : 0);
-        } else {
-            n_extra = pe.nparts - 1u;
-        }
-
-        // lane = part: (bucket, offset of the part inside the query)
-        uint64_t p_src = 0;
-        uint32_t p_cnt = 0, p_delta = 0;
-        uint64_t mm = m;   // multi scheme: cursor of the walk over _optimal_nk_sum[m], last summand first
-        auto load_parts = [&](uint32_t base_part, uint32_t chunk) {
-            if (pe.scheme == KMX_SCHEME_SINGLE) {
-                if (lane < chunk) {
-                    const uint32_t part = base_part + lane;
-                    // j = 1 .. P-1 at j*k (:279-291), then, for a rest, the k-mer that ends the query
-                    const uint64_t start = (part < sP - 1) ? uint64_t(part + 1) * sk : (m - sk);
-                    uint64_t h;
-                    rank_hash(qr + start, sk, sigma, h);
-                    const Run r = probe(sel, h);
-                    p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(start);
-                }
-            } else {
-                // the walk is serial and wave-uniform; lane s keeps step s
-                for (uint32_t s = 0; s < chunk; ++s) {
-                    const KmxPlanEntry e = load_plan(ix, mm);
-                    const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
-                    const uint32_t k = el->k;
-                    mm -= k;                                           // this summand covers [mm, mm + k)
-                    if (lane == s) {
-                        uint64_t h;
-                        rank_hash(qr + mm, k, sigma, h);
-                        const Run r = probe(el, h);                    // search_k, :520
-                        p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(mm);
-                    }
-                }
-            }
-        };
-        auto check_parts = [&](uint32_t chunk, uint32_t p, bool ok) -> bool {
-            for (uint32_t s = 0; s < chunk; ++s) {
-                const uint64_t bs = __shfl(p_src, int(s));
-                const uint32_t bn = __shfl(p_cnt, int(s));
-                const uint32_t dl = __shfl(p_delta, int(s));
-                if (ok) {
-                    const uint32_t x = p + dl;
-                    const uint64_t pos = lower_bound_dev<uint32_t>(arena + bs, bn, x);
-                    ok = pos < bn && arena[bs + pos] == x;             // binary_search :283, lower_bound :544-546
-                }
-                if (!__any(ok)) break;
-            }
-            return ok;
-        };
-
-        const bool one_chunk = n_extra <= KMX_WAVE;
-        if (one_chunk) load_parts(0, n_extra);
+        const uint32_t n_it = fast ? (c0 + KMX_VGROUP - 1) / KMX_VGROUP : 0u;
+        uint32_t max_it = n_it;
+        for (int off = 32; off > 0; off >>= 1) max_it = max(max_it, uint32_t(__shfl_xor(int(max_it), off)));
+        uint64_t word = 0;
         uint32_t valid = 0;
-        for (uint32_t w = 0; w < n_words; ++w) {
-            const uint32_t ci = w * 64 + lane;
-            bool ok = ci < c0;
-            const uint32_t p = ok ? arena[src + ci] : 0;
-            if (one_chunk) {
-                ok = check_parts(n_extra, p, ok);
-            } else {
-                mm = m;
-                for (uint32_t base_part = 0; base_part < n_extra && __any(ok); base_part += KMX_WAVE) {
-                    const uint32_t chunk = min(uint32_t(KMX_WAVE), n_extra - base_part);
-                    load_parts(base_part, chunk);
-                    ok = check_parts(chunk, p, ok);
+        for (uint32_t it = 0; it < max_it; ++it) {
+            const uint32_t ci = it * KMX_VGROUP + gl;
+            bool ok = fast && ci < c0;
+            const uint32_t x = (ok ? arena[src + ci] : 0u) + delta;
+            if (staged) {
+                uint32_t lo = 0, hi = pcnt;                             // lower_bound in LDS
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (stage[wv][g][mid] < x) lo = mid + 1; else hi = mid;
                 }
+                ok = ok && lo < pcnt && stage[wv][g][lo] == x;          // binary_search :283, lower_bound :544-546
+            } else if (ok) {
+                const uint64_t pos = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x);
+                ok = pos < pcnt && arena[p1src + pos] == x;
             }
-            const uint64_t word = __ballot(ok);                        // 64 candidates = one bitset word
-            if (lane == 0) words[w] = word;
-            valid += uint32_t(__popcll(word));
+            const uint64_t bal = __ballot(ok);
+            word |= ((bal >> (KMX_VGROUP * g)) & slice_mask) << (KMX_VGROUP * (it % KMX_VSLICES));
+            if (it < n_it && ((it % KMX_VSLICES) == KMX_VSLICES - 1 || it + 1 == n_it)) {
+                if (gl == 0) words[it / KMX_VSLICES] = word;            // bit i = word i>>6, bit i&63
+                valid += uint32_t(__popcll(word));
+                word = 0;
+            }
         }
-        if (lane == 0) d.cnt[q] = valid;
+        if (fast && gl == 0) {
+            if ((c0 & 63) == 0) words[c0 / 64] = 0;                     // n_bits/64 + 1 words (compressed_bitset.hpp:23)
+            d.cnt[q] = valid;
+        }
+        __builtin_amdgcn_wave_barrier();                                // stage[] is reused by the next round
+
+        // queries with more parts: the whole wave serves them one at a time
+        for (uint32_t e = 0; e < KMX_VGROUPS; ++e) {
+            const uint32_t qe = __shfl(q, int(e * KMX_VGROUP));
+            const int general = __shfl(int(have && !fast), int(e * KMX_VGROUP));
+            if (general) validate_general_wave(ix, arena, qranks, qoff, d, qe, mask_words);
+        }
     }
 }
 
@@ -931,7 +971,7 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words)
 {
-    uint64_t waves = n_stitch;
+    uint64_t waves = (n_stitch + KMX_VGROUPS - 1) / KMX_VGROUPS;        // KMX_VGROUPS queries per wave
     unsigned int blocks = (unsigned int)std::min<uint64_t>((waves + 3) / 4, 256 * 32);
     hipLaunchKernelGGL(k_validate, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
 }
