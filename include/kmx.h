@@ -103,6 +103,12 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
                            uint32_t n_ks, const kmx_options* opts, kmx_index** out);
 void kmx_index_free(kmx_index* index);
 
+/* On-disk image of the flattened index: build once, load many (the intent stated in the thesis,
+ * thesis/content/02_implementation.tex:44-46; not implemented by the reference).  kmx_index_load validates
+ * magic, version, every size field and a checksum before touching the device. */
+kmx_status kmx_index_save(const kmx_index* index, const char* path);
+kmx_status kmx_index_load(const char* path, const kmx_options* opts, kmx_index** out);
+
 /* Introspection of the flattened index (sizes in bytes are device-resident bytes). */
 kmx_status kmx_index_info(const kmx_index* index, uint64_t* n, uint32_t* sigma, uint32_t* n_ks,
                           uint32_t* ks /* KMX_MAX_KS */, uint32_t* table_kinds /* KMX_MAX_KS */,

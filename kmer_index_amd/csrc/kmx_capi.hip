@@ -132,6 +132,10 @@ struct kmx_index {
     KmxIndexDev* d_index = nullptr;     // device copy of the header
     const uint32_t* d_arena = nullptr;  // the position arena (also in the header; passed to kernels directly)
     unsigned long long* d_dbg = nullptr; // KMX_CHECKED violation records
+    struct ElemSizes { size_t n_offs, n_slots, n_ukeys; };
+    std::vector<ElemSizes> elem_sizes;   // element array lengths (for kmx_index_save)
+    std::vector<uint8_t> tail;           // last kmax letters of the text
+    KmxIndexDev h_header{};              // host copy of the device header (holds device pointers)
     kmx::FillVariant fill_variant{12, true};   // 3072-slot tiles (12 gathers in flight per thread), non-temporal stores
     bool rec32 = true;                   // every arena index fits 31 bits
     std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
@@ -204,6 +208,95 @@ kmx_status check_device()
 }
 
 } // namespace
+
+// Uploads flattened element images and everything around them (tail, planner table, header).
+// Shared by kmx_index_build (images fresh from the flatten) and kmx_index_load (images from a file).
+static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const uint8_t* tail_kmax, uint64_t n, uint32_t sigma,
+                                 uint32_t range, int device, const kmx_options& o, kmx_index** out)
+{
+    auto* ix = new kmx_index();
+    ix->device = device;
+    ix->n = n;
+    ix->sigma = sigma;
+    ix->range = range;
+    const uint32_t n_ks = uint32_t(images.size());
+    uint32_t kmax = 0;
+    for (auto& im : images) { ix->ks.push_back(im.k); kmax = std::max(kmax, im.k); }
+    kmx_status st = KMX_OK;
+    auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
+
+    KmxIndexDev h{};
+    h.n = n; h.sigma = sigma; h.n_ks = n_ks; h.kmax = kmax; h.range = range;
+    for (uint32_t j = 0; j < 64; ++j) {
+        // fast_pow(sigma, j); products that leave 64 bits are never reached by a valid k
+        // and are saturated so the fan-out guard (> 1e7) still fires
+        unsigned __int128 v = 1;
+        for (uint32_t t = 0; t < j; ++t) { v *= sigma; if (v > ~uint64_t(0)) { v = ~uint64_t(0); break; } }
+        h.pw[j] = uint64_t(v);
+    }
+    // arena = every element's positions back to back
+    uint64_t arena_elems = 0;
+    for (auto& im : images) arena_elems += im.npos;
+    {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, arena_elems * 4 + 64);   // padded: k_fill reads 16 bytes at any element
+        if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
+        ix->allocs.push_back(p);
+        ix->device_bytes += arena_elems * 4;
+        h.arena = static_cast<const uint32_t*>(p);
+        ix->d_arena = h.arena;
+    }
+    h.arena_elems = arena_elems;
+    ix->rec32 = (arena_elems + 65536) * 4 < (uint64_t(1) << 32);   // 32-bit byte offsets reach the whole arena
+    if (const char* fvs = getenv("KMX_FILL_VARIANT")) {
+        // tuning knob: "<e>[n]", e.g. "8n", "16", "16n"
+        int e = atoi(fvs);
+        if (e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'n') != nullptr};
+    }
+    {
+        void* p = nullptr;
+        if (hipMalloc(&p, 16 * 8) == hipSuccess) { (void)hipMemset(p, 0, 16 * 8); ix->allocs.push_back(p); h.dbg = static_cast<unsigned long long*>(p); ix->d_dbg = h.dbg; }
+    }
+    if (o.keep_host_arena) ix->host_arena.reserve(arena_elems);
+    uint64_t base = 0;
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        auto& im = images[i];
+        KmxElemDev& el = h.elems[i];
+        el.k = im.k; el.table_kind = im.table_kind; el.log2cap = im.log2cap; el.n_ukeys = uint32_t(im.ukeys.size());
+        el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos;
+        ix->table_kinds.push_back(im.table_kind);
+        ix->elem_sizes.push_back({im.offs.size(), im.slots.size(), im.ukeys.size()});
+        hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.npos * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+        if (o.keep_host_arena) ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.end());
+        if ((st = upload(ix, im.offs.data(), im.offs.size(), &el.offs)) != KMX_OK) return bail(st);
+        if (im.table_kind == KMX_TABLE_OPEN) {
+            if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
+            if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
+        }
+        base += im.npos;
+        im = kmx::ElemImage();   // release host memory early
+    }
+    ix->tail.assign(tail_kmax, tail_kmax + kmax);
+    if ((st = upload(ix, tail_kmax, kmax, &h.tail)) != KMX_OK) return bail(st);
+    {
+        std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, range);
+        if ((st = upload(ix, plan.data(), plan.size(), &h.plan)) != KMX_OK) return bail(st);
+    }
+    {
+        const KmxIndexDev* d = nullptr;
+        if ((st = upload(ix, &h, 1, &d)) != KMX_OK) return bail(st);
+        ix->d_index = const_cast<KmxIndexDev*>(d);
+        ix->h_header = h;
+    }
+    {
+        hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("stream: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+    }
+    *out = ix;
+    return KMX_OK;
+}
+
 
 extern "C" {
 
@@ -303,81 +396,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     for (uint32_t i = 0; i < n_ks; ++i)
         if (!oks[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]);
 
-    auto* ix = new kmx_index();
-    ix->device = device;
-    ix->n = n;
-    ix->sigma = sigma;
-    ix->range = range;
-    ix->ks.assign(ks, ks + n_ks);
-    auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
-
-    KmxIndexDev h{};
-    h.n = n; h.sigma = sigma; h.n_ks = n_ks; h.kmax = kmax; h.range = range;
-    for (uint32_t j = 0; j < 64; ++j) {
-        // fast_pow(sigma, j); products that leave 64 bits are never reached by a valid k
-        // and are saturated so the fan-out guard (> 1e7) still fires
-        unsigned __int128 v = 1;
-        for (uint32_t t = 0; t < j; ++t) { v *= sigma; if (v > ~uint64_t(0)) { v = ~uint64_t(0); break; } }
-        h.pw[j] = uint64_t(v);
-    }
-    // arena = every element's positions back to back
-    uint64_t arena_elems = 0;
-    for (auto& im : images) arena_elems += im.npos;
-    {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, arena_elems * 4 + 64);   // padded: k_fill reads 16 bytes at any element
-        if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
-        ix->allocs.push_back(p);
-        ix->device_bytes += arena_elems * 4;
-        h.arena = static_cast<const uint32_t*>(p);
-        ix->d_arena = h.arena;
-    }
-    h.arena_elems = arena_elems;
-    ix->rec32 = (arena_elems + 65536) * 4 < (uint64_t(1) << 32);   // 32-bit byte offsets reach the whole arena
-    if (const char* fvs = getenv("KMX_FILL_VARIANT")) {
-        // tuning knob: "<e>[n]", e.g. "8n", "16", "16n"
-        int e = atoi(fvs);
-        if (e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'n') != nullptr};
-    }
-    {
-        void* p = nullptr;
-        if (hipMalloc(&p, 16 * 8) == hipSuccess) { (void)hipMemset(p, 0, 16 * 8); ix->allocs.push_back(p); h.dbg = static_cast<unsigned long long*>(p); ix->d_dbg = h.dbg; }
-    }
-    if (o.keep_host_arena) ix->host_arena.reserve(arena_elems);
-    uint64_t base = 0;
-    for (uint32_t i = 0; i < n_ks; ++i) {
-        auto& im = images[i];
-        KmxElemDev& el = h.elems[i];
-        el.k = im.k; el.table_kind = im.table_kind; el.log2cap = im.log2cap; el.n_ukeys = uint32_t(im.ukeys.size());
-        el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos;
-        ix->table_kinds.push_back(im.table_kind);
-        hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.npos * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
-        if (o.keep_host_arena) ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.end());
-        if ((st = upload(ix, im.offs.data(), im.offs.size(), &el.offs)) != KMX_OK) return bail(st);
-        if (im.table_kind == KMX_TABLE_OPEN) {
-            if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
-            if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
-        }
-        base += im.npos;
-        im = kmx::ElemImage();   // release host memory early
-    }
-    if ((st = upload(ix, ranks + (n - kmax), kmax, &h.tail)) != KMX_OK) return bail(st);
-    {
-        std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, range);
-        if ((st = upload(ix, plan.data(), plan.size(), &h.plan)) != KMX_OK) return bail(st);
-    }
-    {
-        const KmxIndexDev* d = nullptr;
-        if ((st = upload(ix, &h, 1, &d)) != KMX_OK) return bail(st);
-        ix->d_index = const_cast<KmxIndexDev*>(d);
-    }
-    {
-        hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("stream: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
-    }
-    *out = ix;
-    return KMX_OK;
+    return install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out);
 }
 
 void kmx_index_free(kmx_index* ix)
@@ -707,3 +726,161 @@ void kmx_result_free(kmx_result* r)
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------
+// On-disk image of the flattened index (the thesis states the intent — "the index is serialized so
+// it can be loaded directly at a later point", thesis/content/02_implementation.tex:44-46 — the
+// reference never implemented it).  Layout, all little endian, sections padded to 8 bytes:
+//   FileHeader | FileElem[n_ks] | tail[kmax] | per element: positions, offs, slots, ukeys
+// The checksum covers everything after the header.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct FileHeader {
+    char magic[8];          // "KMXIMG01"
+    uint32_t version;       // 1
+    uint32_t sigma;
+    uint64_t n;
+    uint32_t n_ks;
+    uint32_t range;
+    uint32_t kmax;
+    uint32_t reserved;
+    uint64_t checksum;
+};
+struct FileElem {
+    uint32_t k, table_kind, log2cap, reserved;
+    uint64_t n_keys, npos, n_offs, n_slots, n_ukeys;
+};
+
+struct Mixer {                       // word-wise 64-bit checksum (order sensitive)
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    void add(const void* p, size_t bytes)
+    {
+        const unsigned char* b = static_cast<const unsigned char*>(p);
+        size_t i = 0;
+        for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001B3ull; h ^= h >> 29; }
+        uint64_t w = 0;
+        if (i < bytes) { memcpy(&w, b + i, bytes - i); h = (h ^ w) * 0x100000001B3ull; h ^= h >> 29; }
+    }
+};
+
+bool write_section(FILE* f, Mixer& mx, const void* p, size_t bytes)
+{
+    static const char zero[8] = {0};
+    mx.add(p, bytes);
+    if (bytes && fwrite(p, 1, bytes, f) != bytes) return false;
+    size_t pad = (8 - bytes % 8) % 8;
+    return pad == 0 || fwrite(zero, 1, pad, f) == pad;
+}
+
+bool read_section(FILE* f, Mixer& mx, void* p, size_t bytes)
+{
+    char skip[8];
+    if (bytes && fread(p, 1, bytes, f) != bytes) return false;
+    mx.add(p, bytes);
+    size_t pad = (8 - bytes % 8) % 8;
+    return pad == 0 || fread(skip, 1, pad, f) == pad;
+}
+
+} // namespace
+
+extern "C" kmx_status kmx_index_save(const kmx_index* ix, const char* path)
+{
+    if (!ix || !path) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_save: NULL argument");
+    HIP_TRY(hipSetDevice(ix->device));
+    HIP_TRY(hipDeviceSynchronize());
+    FILE* f = fopen(path, "wb");
+    if (!f) return fail(KMX_ERR_INVALID_ARGUMENT, std::string("kmx_index_save: cannot open ") + path);
+    const uint32_t n_ks = uint32_t(ix->ks.size());
+    FileHeader fh{};
+    memcpy(fh.magic, "KMXIMG01", 8);
+    fh.version = 1; fh.sigma = ix->sigma; fh.n = ix->n; fh.n_ks = n_ks; fh.range = ix->range; fh.kmax = ix->h_header.kmax;
+    bool ok = fwrite(&fh, sizeof fh, 1, f) == 1;
+    Mixer mx;
+    std::vector<FileElem> fes(n_ks);
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        const KmxElemDev& el = ix->h_header.elems[i];
+        fes[i] = FileElem{el.k, el.table_kind, el.log2cap, 0, el.n_keys, el.npos, ix->elem_sizes[i].n_offs, ix->elem_sizes[i].n_slots,
+                          ix->elem_sizes[i].n_ukeys};
+    }
+    ok = ok && write_section(f, mx, fes.data(), fes.size() * sizeof(FileElem));
+    ok = ok && write_section(f, mx, ix->tail.data(), ix->tail.size());
+    std::vector<unsigned char> buf;
+    auto dump = [&](const void* dptr, size_t bytes) -> kmx_status {
+        buf.resize(bytes);
+        if (bytes) HIP_TRY(hipMemcpy(buf.data(), dptr, bytes, hipMemcpyDeviceToHost));
+        if (!write_section(f, mx, buf.data(), bytes)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_save: write failed");
+        return KMX_OK;
+    };
+    kmx_status st = ok ? KMX_OK : fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_save: write failed");
+    for (uint32_t i = 0; i < n_ks && st == KMX_OK; ++i) {
+        const KmxElemDev& el = ix->h_header.elems[i];
+        st = dump(ix->d_arena + el.arena_base, el.npos * 4);
+        if (st == KMX_OK) st = dump(el.offs, ix->elem_sizes[i].n_offs * 4);
+        if (st == KMX_OK) st = dump(el.slots, ix->elem_sizes[i].n_slots * sizeof(KmxSlot));
+        if (st == KMX_OK) st = dump(el.ukeys, ix->elem_sizes[i].n_ukeys * 8);
+    }
+    if (st == KMX_OK) {
+        fh.checksum = mx.h;
+        if (fseek(f, 0, SEEK_SET) != 0 || fwrite(&fh, sizeof fh, 1, f) != 1) st = fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_save: write failed");
+    }
+    if (fclose(f) != 0 && st == KMX_OK) st = fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_save: close failed");
+    return st;
+}
+
+extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, kmx_index** out)
+{
+    if (!path || !out) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: NULL argument");
+    *out = nullptr;
+    kmx_options o{};
+    o.device = -1;
+    if (opts) {
+        if (opts->struct_size != sizeof(kmx_options)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: options.struct_size mismatch");
+        o = *opts;
+    }
+    FILE* f = fopen(path, "rb");
+    if (!f) return fail(KMX_ERR_INVALID_ARGUMENT, std::string("kmx_index_load: cannot open ") + path);
+    struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
+    FileHeader fh{};
+    if (fread(&fh, sizeof fh, 1, f) != 1 || memcmp(fh.magic, "KMXIMG01", 8) != 0 || fh.version != 1)
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: not a kmx index image (bad magic / version)");
+    if (fh.n_ks == 0 || fh.n_ks > KMX_MAX_KS || fh.kmax == 0 || fh.kmax > 63 || fh.n < fh.kmax || fh.n + fh.kmax - 1 >= 0xFFFFFFFFull ||
+        fh.range == 0 || fh.range > 65535 * 9u)
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: corrupt header");
+    Mixer mx;
+    std::vector<FileElem> fes(fh.n_ks);
+    if (!read_section(f, mx, fes.data(), fes.size() * sizeof(FileElem))) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
+    uint32_t kmax = 0;
+    for (const FileElem& fe : fes) {
+        const bool dense = fe.table_kind == KMX_TABLE_DENSE, open = fe.table_kind == KMX_TABLE_OPEN;
+        if (!kmx::k_is_valid(fh.sigma, fe.k) || fe.npos != fh.n - fe.k + 1 || fe.n_keys != kmx::fast_pow(fh.sigma, uint8_t(fe.k)) || !(dense || open) ||
+            (dense && (fe.n_offs != fe.n_keys + 1 || fe.n_slots || fe.n_ukeys)) ||
+            (open && (fe.n_offs != fe.n_ukeys + 1 || fe.log2cap > 40 || fe.n_slots != (uint64_t(1) << fe.log2cap) || fe.n_ukeys > fe.npos)))
+            return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: corrupt element table");
+        kmax = std::max(kmax, fe.k);
+    }
+    if (kmax != fh.kmax) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: corrupt header (kmax)");
+    std::vector<uint8_t> tail(fh.kmax);
+    if (!read_section(f, mx, tail.data(), tail.size())) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
+    std::vector<kmx::ElemImage> images(fh.n_ks);
+    for (uint32_t i = 0; i < fh.n_ks; ++i) {
+        const FileElem& fe = fes[i];
+        kmx::ElemImage& im = images[i];
+        im.k = fe.k; im.table_kind = fe.table_kind; im.log2cap = fe.log2cap; im.n_keys = fe.n_keys; im.npos = fe.npos;
+        try {
+            im.positions.resize(fe.npos); im.offs.resize(fe.n_offs); im.slots.resize(fe.n_slots); im.ukeys.resize(fe.n_ukeys);
+        } catch (const std::bad_alloc&) {
+            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_index_load: host allocation failed");
+        }
+        if (!read_section(f, mx, im.positions.data(), fe.npos * 4) || !read_section(f, mx, im.offs.data(), fe.n_offs * 4) ||
+            !read_section(f, mx, im.slots.data(), fe.n_slots * sizeof(KmxSlot)) || !read_section(f, mx, im.ukeys.data(), fe.n_ukeys * 8))
+            return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
+    }
+    if (mx.h != fh.checksum) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: checksum mismatch (corrupt image)");
+    kmx_status st = check_device();
+    if (st != KMX_OK) return st;
+    int device = o.device;
+    if (device < 0) HIP_TRY(hipGetDevice(&device));
+    HIP_TRY(hipSetDevice(device));
+    return install_images_impl(images, tail.data(), fh.n, fh.sigma, o.query_size_range ? o.query_size_range : fh.range, device, o, out);
+}

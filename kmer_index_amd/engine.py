@@ -19,7 +19,7 @@ Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
 
 # every symbol include/kmx.h declares
 EXPORTS = [
-    "kmx_index_build", "kmx_index_free", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_plan", "kmx_fast_pow",
+    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_plan", "kmx_fast_pow",
     "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
@@ -64,6 +64,10 @@ def lib():
         L.kmx_index_build.restype = C.c_int
         L.kmx_index_build.argtypes = [vp, u64, u32, vp, u32, P(Options), P(vp)]
         L.kmx_index_free.argtypes = [vp]
+        L.kmx_index_save.restype = C.c_int
+        L.kmx_index_save.argtypes = [vp, C.c_char_p]
+        L.kmx_index_load.restype = C.c_int
+        L.kmx_index_load.argtypes = [C.c_char_p, P(Options), P(vp)]
         L.kmx_index_info.restype = C.c_int
         L.kmx_index_info.argtypes = [vp, P(u64), P(u32), P(u32), vp, vp, P(u64)]
         L.kmx_index_arena_host.restype = C.c_int
@@ -214,6 +218,23 @@ class Index:
         self._h = C.c_void_p()
         _check(lib().kmx_index_build(ranks.ctypes.data, ranks.size, self.sigma, ks.ctypes.data, ks.size,
                                      C.byref(o), C.byref(self._h)))
+
+    @classmethod
+    def load(cls, path, device=-1, keep_host_arena=False):
+        """kmx_index_load: an index from an image written by save()."""
+        self = cls.__new__(cls)
+        o = Options()
+        o.struct_size = C.sizeof(Options)
+        o.device = device
+        o.keep_host_arena = int(keep_host_arena)
+        self._h = C.c_void_p()
+        _check(lib().kmx_index_load(os.fsencode(path), C.byref(o), C.byref(self._h)))
+        info = self.info()
+        self.ks, self.sigma, self.n = info["ks"], info["sigma"], info["n"]
+        return self
+
+    def save(self, path):
+        _check(lib().kmx_index_save(self._h, os.fsencode(path)))
 
     def info(self):
         n, sigma, nks, dbytes = C.c_uint64(), C.c_uint32(), C.c_uint32(), C.c_uint64()

@@ -98,3 +98,21 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"\boracle\b|liboracle|orc_", txt):
                         bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_index_load_rejects_bad_images_before_touching_the_device(engine, tmp_path):
+    """kmx_index_load validates magic / sizes / checksum on the host (no GPU needed to refuse a file)."""
+    bad = tmp_path / "garbage.kmx"
+    bad.write_bytes(b"not an index image at all" * 10)
+    with pytest.raises(engine.KmxError) as e:
+        engine.Index.load(str(bad))
+    assert e.value.status == 1 and "magic" in str(e.value)
+    with pytest.raises(engine.KmxError) as e:
+        engine.Index.load(str(tmp_path / "missing.kmx"))
+    assert e.value.status == 1
+    trunc = tmp_path / "trunc.kmx"
+    import struct
+    trunc.write_bytes(b"KMXIMG01" + struct.pack("<IIQIIIIQ", 1, 4, 1000, 1, 10000, 5, 0, 0))
+    with pytest.raises(engine.KmxError) as e:
+        engine.Index.load(str(trunc))
+    assert e.value.status == 1 and "truncated" in str(e.value)

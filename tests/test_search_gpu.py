@@ -228,3 +228,32 @@ def test_concurrent_host_threads_share_one_index(engine, orc):
     for th in threads:
         th.join()
     assert not errors, errors
+
+
+@pytest.mark.parametrize("table", ["open", "dense"])
+def test_save_load_roundtrip(engine, orc, tmp_path, table):
+    """kmx_index_save / kmx_index_load: the loaded image answers exactly like the built index; corruption is detected."""
+    text = synth.ranks(2718, 150_000, 5)
+    ks = [6, 9]
+    tk = engine.TABLE_OPEN if table == "open" else engine.TABLE_DENSE
+    idx = engine.Index(text, 5, ks, table=tk)
+    qranks, qoff = make_queries(text, 5, [3, 6, 9, 12, 15, 18, 21], 30, seed=8)
+    a = idx.search(qranks, qoff).host()
+    path = tmp_path / "index.kmx"
+    idx.save(str(path))
+    idx.close()
+    idx2 = engine.Index.load(str(path))
+    assert idx2.info()["ks"] == ks and idx2.info()["n"] == text.size and idx2.info()["tables"] == [tk, tk]
+    b = idx2.search(qranks, qoff).host()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    o_off, o_pos, _, _ = orc.Index(text, 5, ks).search_batch(qranks, qoff, n_threads=4)
+    assert np.array_equal(b[0], o_off) and np.array_equal(b[1], o_pos)
+    # flip one byte in the middle of the payload: checksum mismatch
+    raw = bytearray(path.read_bytes())
+    raw[len(raw) // 2] ^= 0x40
+    bad = tmp_path / "bad.kmx"
+    bad.write_bytes(bytes(raw))
+    with pytest.raises(engine.KmxError) as e:
+        engine.Index.load(str(bad))
+    assert "checksum" in str(e.value) or "corrupt" in str(e.value)
