@@ -248,6 +248,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     }
     h.arena_elems = arena_elems;
     ix->rec32 = (arena_elems + 65536) * 4 < (uint64_t(1) << 32);   // 32-bit byte offsets reach the whole arena
+    if (const char* f64 = getenv("KMX_FORCE_REC64")) { if (atoi(f64)) ix->rec32 = false; }   // test hook: the >= 4 GiB arena path
     if (const char* fvs = getenv("KMX_FILL_VARIANT")) {
         // tuning knob: "<e>[n]", e.g. "8n", "16", "16n"
         int e = atoi(fvs);

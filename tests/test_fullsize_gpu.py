@@ -144,3 +144,24 @@ def test_cfg5_aa20_k5_full(engine, orc):
     oidx = orc.Index(text, sigma, [k])
     o_off, o_pos, _, _ = oidx.search_batch(q[:200_000 * k], off[:200_001], n_threads=8)
     assert np.array_equal(o_off, hit_off[:200_001]) and np.array_equal(o_pos, positions[:int(hit_off[200_000])])
+
+
+def test_more_than_2_to_32_hits(engine, orc):
+    """A batch whose hit total exceeds 2^32: 64-bit offsets end to end (3.2e6 8-mers on the 1e8-bp text, ~4.9e9 hits)."""
+    n, k, sigma, nq = 100_000_000, 8, 4, 3_200_000
+    text = synth.ranks(1003, n, sigma)
+    q, off = synth.uniform_queries(4242, nq, k, sigma)
+    idx = engine.Index(text, sigma, [k])
+    per_key = np.bincount(kmer_hashes(text, k, sigma).astype(np.int64), minlength=sigma ** k)
+    want = per_key[query_hashes(q, k, sigma).astype(np.int64)].astype(np.uint64)
+    assert int(want.sum()) > (1 << 32)
+    res = idx.search(q, off, flags=engine.SEARCH_COUNT_ONLY)
+    ho = res.host()[0]
+    assert np.array_equal(np.diff(ho), want) and int(ho[-1]) == int(want.sum())
+    res.close()
+    res = idx.search(q, off)
+    hit_off, positions, status, kinds = res.host()
+    assert np.array_equal(hit_off, ho) and positions.size == int(want.sum())
+    rng = np.random.default_rng(17)
+    sample = np.concatenate([rng.integers(0, nq, 3000), np.arange(nq - 200, nq)])     # incl. lists beyond offset 2^32
+    check_lists(text, q.reshape(-1, k), hit_off, positions, sample)

@@ -257,3 +257,35 @@ def test_save_load_roundtrip(engine, orc, tmp_path, table):
     with pytest.raises(engine.KmxError) as e:
         engine.Index.load(str(bad))
     assert "checksum" in str(e.value) or "corrupt" in str(e.value)
+
+
+def test_large_k_sort_based_flatten_and_rec64(engine, orc):
+    """Key spaces far beyond a histogram (4^20, 4^31 keys): the sort-based flatten + open table; and the 64-bit
+    LDS-record variant of k_fill that serves arenas >= 4 GiB (forced here through its test hook)."""
+    import os
+    text = synth.ranks(161, 150_000, 4)
+    for ks, lengths in (([20], [9, 15, 20, 25, 40, 45]), ([31], [20, 31, 40, 62, 70]), ([16, 20], [16, 20, 32, 36, 40])):
+        qranks, qoff = make_queries(text, 4, lengths, 24, seed=ks[0])
+        oidx = orc.Index(text, 4, ks)
+        o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+        for rec64 in ("0", "1"):
+            os.environ["KMX_FORCE_REC64"] = rec64
+            try:
+                idx = engine.Index(text, 4, ks)
+            finally:
+                os.environ.pop("KMX_FORCE_REC64", None)
+            assert idx.info()["tables"] == [engine.TABLE_OPEN] * len(ks)
+            ho, pos, st, kd = idx.search(qranks, qoff).host()
+            assert np.array_equal(st, o_st.astype(np.uint8)), (ks, rec64)
+            assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), (ks, rec64)
+            idx.close()
+    # the rec64 variant on a batch with many tiles
+    os.environ["KMX_FORCE_REC64"] = "1"
+    try:
+        idx = engine.Index(text, 4, [6])
+    finally:
+        os.environ.pop("KMX_FORCE_REC64", None)
+    q, off = synth.uniform_queries(3, 50_000, 6, 4)
+    ho, pos, st, kd = idx.search(q, off).host()
+    o_off, o_pos, _, _ = orc.Index(text, 4, [6]).search_batch(q, off, n_threads=8)
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
