@@ -120,14 +120,33 @@ __device__ __forceinline__ uint64_t upper_bound_dev(P a, uint64_t n, T x)
 // rank-hash of `len` letters by Horner's rule; equals sum r_i * sigma^(len-i-1)
 // (kmer_index.hpp:56-73) because k < 64/log2(sigma) rules out wrap-around.
 // Returns false when a letter is not a valid rank.
-__device__ __forceinline__ bool rank_hash(const uint8_t* __restrict__ q, uint32_t len, uint32_t sigma, uint64_t& h)
+// The letters are fetched 16 at a time with one byte-aligned 16-byte load (instead of one load
+// per letter) whenever those 16 bytes lie inside the query buffer [.., qend).
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+__device__ __forceinline__ bool rank_hash(const uint8_t* __restrict__ q, uint32_t len, uint32_t sigma, uint64_t& h,
+                                          const uint8_t* __restrict__ qend)
 {
     uint64_t acc = 0;
     bool ok = true;
-    for (uint32_t i = 0; i < len; ++i) {
-        uint32_t r = q[i];
-        ok &= r < sigma;
-        acc = acc * sigma + r;
+    for (uint32_t c = 0; c < len; c += 16) {
+        const uint32_t nb = min(16u, len - c);
+        if (q + c + 16 <= qend) {
+            const u32x4_a1 w = *reinterpret_cast<const u32x4_a1*>(q + c);
+            uint64_t lo = uint64_t(w[0]) | (uint64_t(w[1]) << 32), hi = uint64_t(w[2]) | (uint64_t(w[3]) << 32);
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t r = uint32_t(lo & 0xFF);
+                lo = (lo >> 8) | (hi << 56);
+                hi >>= 8;
+                ok &= r < sigma;
+                acc = acc * sigma + r;
+            }
+        } else {
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t r = q[c + j];
+                ok &= r < sigma;
+                acc = acc * sigma + r;
+            }
+        }
     }
     h = acc;
     return ok;
@@ -150,11 +169,19 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                                                       QueryDesc d, unsigned long long* __restrict__ ctr)
 {
     __shared__ BlockCounters bc;
+    __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
         bc.n_stitch = bc.n_prefix = bc.n_error = bc.n_none = 0;
         bc.words = bc.pelems = 0;
         bc.max_runs = 0;
     }
+    {
+        const uint32_t n_words = ix->n_ks * uint32_t(sizeof(KmxElemDev) / 8);
+        const uint64_t* __restrict__ srcw = reinterpret_cast<const uint64_t*>(ix->elems);
+        uint64_t* dstw = reinterpret_cast<uint64_t*>(elems_s);
+        for (uint32_t i = threadIdx.x; i < n_words; i += KMX_BLOCK) dstw[i] = srcw[i];
+    }
+    const uint8_t* __restrict__ qend = qranks + qoff[nq];
     __syncthreads();
 
     // a block serves KMX_LOOKUP_ITEMS * 256 queries so that the (returning) global atomics of the
@@ -185,11 +212,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             const KmxPlanEntry pe = load_plan(ix, m);
             bool ranks_ok = true;
             if (pe.scheme == KMX_SCHEME_SINGLE) {
-                const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
+                const KmxElemDev* el = &elems_s[pe.elem];
                 const uint32_t k = el->k;
                 if (m == k) {                                 // :198-205
                     uint64_t h;
-                    ranks_ok = rank_hash(qr, k, sigma, h);
+                    ranks_ok = rank_hash(qr, k, sigma, h, qend);
                     if (ranks_ok) {
                         Run r = probe(el, h);
                         if (r.cnt) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }
@@ -200,7 +227,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                         status = KMX_Q_SUBK_FANOUT;           // :119-122
                     } else {
                         uint64_t hp;
-                        ranks_ok = rank_hash(qr, uint32_t(m), sigma, hp);
+                        ranks_ok = rank_hash(qr, uint32_t(m), sigma, hp, qend);
                         if (ranks_ok) {
                             hp *= R;                          // prefix_hash, :124-129
                             uint64_t klo, khi;                // key-index range of the prefix
@@ -239,7 +266,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                     uint32_t extra_delta = 0;
                     for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
                         uint64_t h;
-                        ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h);
+                        ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h, qend);
                         if (!ranks_ok) break;
                         Run r = probe(el, h);
                         if (j == 0) first = r; else { extra = r; extra_delta = j * k; }
@@ -252,7 +279,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                             if (rest) {
                                 // the rest is verified through the k-mer that ENDS the query
                                 uint64_t h;
-                                ranks_ok = rank_hash(qr + (m - k), k, sigma, h);
+                                ranks_ok = rank_hash(qr + (m - k), k, sigma, h, qend);
                                 if (ranks_ok) { extra = probe(el, h); extra_delta = uint32_t(m - k); }
                                 all = ranks_ok && extra.cnt != 0;
                             }
@@ -272,11 +299,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                 const uint32_t nparts = pe.nparts;
                 for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
                     const KmxPlanEntry e = load_plan(ix, mm);
-                    const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
+                    const KmxElemDev* el = &elems_s[e.elem];
                     const uint32_t k = el->k;
                     mm -= k;                                  // this summand covers [mm, mm + k)
                     uint64_t h;
-                    ranks_ok = rank_hash(qr + mm, k, sigma, h);
+                    ranks_ok = rank_hash(qr + mm, k, sigma, h, qend);
                     if (!ranks_ok) break;
                     r = probe(el, h);                         // search_k, :183-190 / :520
                     if (j == 0) { extra = r; extra_delta = uint32_t(mm); }
@@ -384,6 +411,7 @@ __device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const 
     const uint64_t b = qoff[q];
     const uint64_t m = qoff[q + 1] - b;
     const uint8_t* __restrict__ qr = qranks + b;
+    const uint8_t* __restrict__ qend = qr + m;                         // wide letter loads stay inside this query
     const KmxPlanEntry pe = load_plan(ix, m);
 
     // parts beyond the first one
@@ -409,7 +437,7 @@ __device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const 
                 // j = 1 .. P-1 at j*k (:279-291), then, for a rest, the k-mer that ends the query
                 const uint64_t start = (part < sP - 1) ? uint64_t(part + 1) * sk : (m - sk);
                 uint64_t h;
-                rank_hash(qr + start, sk, sigma, h);
+                rank_hash(qr + start, sk, sigma, h, qend);
                 const Run r = probe(sel, h);
                 p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(start);
             }
@@ -422,7 +450,7 @@ __device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const 
                 mm -= k;                                           // this summand covers [mm, mm + k)
                 if (lane == s) {
                     uint64_t h;
-                    rank_hash(qr + mm, k, sigma, h);
+                    rank_hash(qr + mm, k, sigma, h, qend);
                     const Run r = probe(el, h);                    // search_k, :520
                     p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(mm);
                 }
