@@ -189,7 +189,7 @@ template <typename T>
 kmx_status upload(kmx_index* ix, const T* host, size_t count, const T** dev_out)
 {
     void* p = nullptr;
-    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16) + 16;   // +16: tables are probed with 16-byte loads
     HIP_TRY(hipMalloc(&p, bytes));
     ix->allocs.push_back(p);
     ix->device_bytes += bytes;

@@ -189,8 +189,111 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     uint8_t kinds[KMX_LOOKUP_ITEMS];
     unsigned int locs[KMX_LOOKUP_ITEMS];
     unsigned long long locw[KMX_LOOKUP_ITEMS];
+    bool done[KMX_LOOKUP_ITEMS];
+
+    // ---- pass 1: the plain exact lookup (m == k <= 16, :198-205), the thread's queries INTERLEAVED:
+    // all offsets, then all plan entries, then all letter loads, then all probes — one memory round
+    // trip per phase instead of one per query and phase.
+    {
+        const uint32_t sigma = ix->sigma, range = ix->range;
+        const uint8_t* __restrict__ dummy = reinterpret_cast<const uint8_t*>(ix);     // always >= 16 readable bytes
+        uint64_t qb[KMX_LOOKUP_ITEMS];
+        uint32_t qm[KMX_LOOKUP_ITEMS];
+        uint32_t praw[KMX_LOOKUP_ITEMS];
+        u32x4_a1 w[KMX_LOOKUP_ITEMS];
+        uint64_t hs[KMX_LOOKUP_ITEMS];
+        bool rok[KMX_LOOKUP_ITEMS];
+        u32x4_a1 pr[KMX_LOOKUP_ITEMS];
+        unsigned int n_none = 0, n_err = 0;
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            const uint64_t qq = q < nq ? q : nq - 1;
+            qb[it] = qoff[qq];
+            const uint64_t mlen = qoff[qq + 1] - qb[it];
+            qm[it] = mlen > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(mlen);
+        }
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it)
+            praw[it] = ((const KMX_GLOBAL uint32_t*)ix->plan)[min(qm[it], range - 1)];
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
+            done[it] = q < nq && qm[it] > 0 && qm[it] < range && (praw[it] & 0xFF) == KMX_SCHEME_SINGLE && el->k == qm[it] &&
+                       qm[it] <= 16 && qranks + qb[it] + 16 <= qend;
+            w[it] = *reinterpret_cast<const u32x4_a1*>(done[it] ? qranks + qb[it] : dummy);
+        }
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
+            uint64_t lo = uint64_t(w[it][0]) | (uint64_t(w[it][1]) << 32), hi = uint64_t(w[it][2]) | (uint64_t(w[it][3]) << 32);
+            uint64_t acc = 0;
+            bool ok = true;
+            const uint32_t len = done[it] ? qm[it] : 0u;
+            for (uint32_t j = 0; j < len; ++j) {
+                const uint32_t r = uint32_t(lo & 0xFF);
+                lo = (lo >> 8) | (hi << 56);
+                hi >>= 8;
+                ok &= r < sigma;
+                acc = acc * sigma + r;
+            }
+            hs[it] = acc;
+            rok[it] = ok;
+            // first probe: dense -> offs[h], offs[h+1]; open -> the slot {key, off, cnt}; both as one 16-byte load
+            const char* addr = reinterpret_cast<const char*>(dummy);
+            if (done[it] && ok) {
+                if (el->table_kind == KMX_TABLE_DENSE) addr = reinterpret_cast<const char*>(el->offs + acc);
+                else addr = reinterpret_cast<const char*>(el->slots + slot_hash_dev(acc, el->log2cap));
+            }
+            pr[it] = *(const KMX_GLOBAL u32x4_a1*)addr;
+        }
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+            kinds[it] = KMX_KIND_NONE;
+            locs[it] = 0;
+            locw[it] = 0;
+            if (!done[it]) continue;
+            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
+            uint64_t src = 0;
+            uint32_t cnt = 0;
+            uint8_t status = KMX_Q_OK;
+            if (!rok[it]) {
+                status = KMX_Q_BAD_RANK;
+            } else if (el->table_kind == KMX_TABLE_DENSE) {
+                src = el->arena_base + pr[it][0];
+                cnt = pr[it][1] - pr[it][0];
+            } else {
+                // linear probing continues from the prefetched slot (at(hash), :76-84)
+                const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);
+                const uint64_t mask = (uint64_t(1) << el->log2cap) - 1;
+                uint64_t s = slot_hash_dev(hs[it], el->log2cap);
+                uint64_t key = uint64_t(pr[it][0]) | (uint64_t(pr[it][1]) << 32);
+                uint32_t off = pr[it][2], c = pr[it][3];
+                while (c != 0 && key != hs[it]) {
+                    s = (s + 1) & mask;
+                    const u64x2 raw = *(const KMX_GLOBAL u64x2*)(slots + s);
+                    key = raw.x; off = uint32_t(raw.y); c = uint32_t(raw.y >> 32);
+                }
+                if (c) { src = el->arena_base + off; cnt = c; }
+            }
+            const uint8_t kind = cnt ? KMX_KIND_EXACT : KMX_KIND_NONE;
+            n_err += status != KMX_Q_OK;
+            n_none += status == KMX_Q_OK && !cnt;
+            d.src[q] = src;
+            d.cnt[q] = cnt;
+            d.kind[q] = kind;
+            d.status[q] = status;
+        }
+        if (n_err) atomicAdd(&bc.n_error, n_err);
+        if (n_none) atomicAdd(&bc.n_none, n_none);
+    }
+
+    // ---- pass 2: everything else (other lengths, multi-k schemes, long queries), one query at a time
 #pragma unroll 1
     for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+    if (done[it]) continue;
     const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
     uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
     uint64_t src = 0, aux = 0, key = 0;
