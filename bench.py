@@ -31,7 +31,10 @@ def main():
                     help="BASELINE.json configs[N-1]; 2 = the metric's workload (default), 3/4/5 are informational")
     ap.add_argument("--n", type=int, default=0, help="text length (0 = the config's)")
     ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (0 = the config's)")
-    ap.add_argument("--table", choices=["open", "dense", "auto"], default="open")
+    ap.add_argument("--table", choices=["open", "dense", "auto"], default="auto",
+                    help="auto = the engine's default policy (direct addressing when sigma^k <= 4(n-k+1), else open addressing)")
+    ap.add_argument("--no-open-compare", action="store_true",
+                    help="skip the extra leg that times the same workload on the open-addressing table (N=1, config 2 only)")
     ap.add_argument("--gather", choices=["totals", "hits"], default="totals",
                     help="totals: hit lists stay sharded where they were produced, per-shard totals exchanged after the timed region "
                          "(default, zero data-path collective); hits: RCCL gatherv of every hit list to rank 0 inside each step")
@@ -150,6 +153,25 @@ def main():
         total_hits = int(totals[:, 1].sum())
     elapsed = float(t_el.item())
 
+    # ---- the literal north_star variant (open-addressing probe) on the same workload, outside the timed region ----
+    open_leg = None
+    if world == 1 and args.config == 2 and not args.no_open_compare and info["tables"] != [engine.TABLE_OPEN] * len(ks):
+        idx_o = engine.Index(text, args.sigma, ks, table=engine.TABLE_OPEN, device=dev_index)
+        res_o = engine.Result()
+        for _ in range(args.warmup):
+            idx_o.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=t_streams[0].cuda_stream, result=res_o)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            idx_o.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=t_streams[0].cuda_stream, result=res_o)
+        torch.cuda.synchronize()
+        dt_o = time.perf_counter() - t1
+        same = res_o.counts()["n_hits"] == counts["n_hits"]
+        open_leg = {"value": round(nq * args.steps / dt_o / 1e6, 3), "unit": "M queries/s", "ms_per_step": round(dt_o / args.steps * 1e3, 4),
+                    "table": "open addressing, 16-B slots, load <= 0.5", "same_hit_total": bool(same)}
+        res_o.close()
+        idx_o.close()
+
     # ---- verification of a sample against the CPU oracle (after the timed region) ----
     verified = None
     cpu_baseline = None
@@ -223,7 +245,8 @@ def main():
             "dtype": "u32/u64",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{args.config - 1}]: sigma={args.sigma} text {args.n} letters, ks={ks}, {nq} queries per GPU per step "
-                                   f"(lengths {qlens}, planted share {planted}), materialised sorted position lists (to_vector), table={args.table}",
+                                   f"(lengths {qlens}, planted share {planted}), materialised sorted position lists (to_vector), table={args.table}"
+                                   f"{'(dense)' if info['tables'][0] == engine.TABLE_DENSE else '(open)'}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
                        "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated", "gather": args.gather, "streams": n_streams},
             "roofline": {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -231,6 +254,7 @@ def main():
                          "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),
                          "job_algorithmic_GBps": round(job_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                          "job_frac": round(job_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+            "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
             "kernels_avg_ms": kernels_ms,
             "verified_vs_oracle": verified,

@@ -51,6 +51,12 @@ namespace kmer
         const std::uint32_t* _arena = nullptr;
         std::size_t _query_size_range = KMX_QUERY_SIZE_RANGE;
 
+        explicit kmer_index(kmx_index* adopted) : _index(adopted)
+        {
+            std::uint64_t n_elems = 0;
+            detail::throw_on(kmx_index_arena_host(adopted, &_arena, &n_elems), "kmer_index");
+        }
+
     public:
         using result_t = detail::kmer_index_result<position_t>;
 
@@ -73,6 +79,31 @@ namespace kmer
             _index.reset(raw);
             std::uint64_t n_elems = 0;
             detail::throw_on(kmx_index_arena_host(raw, &_arena, &n_elems), "kmer_index");
+        }
+
+        // Build once, load many: the flattened image on disk (the thesis' stated intent,
+        // thesis/content/02_implementation.tex:44-46).  The ks of the image must be this type's ks.
+        void save(const std::string& path) const
+        {
+            detail::throw_on(kmx_index_save(_index.get(), path.c_str()), "kmer_index::save");
+        }
+
+        static kmer_index load(const std::string& path)
+        {
+            kmx_options opts{};
+            opts.struct_size = sizeof(kmx_options);
+            opts.device = -1;
+            opts.keep_host_arena = 1;
+            kmx_index* raw = nullptr;
+            detail::throw_on(kmx_index_load(path.c_str(), &opts, &raw), "kmer_index::load");
+            kmer_index out(raw);
+            std::uint32_t sigma = 0, n_ks = 0, file_ks[KMX_MAX_KS] = {};
+            detail::throw_on(kmx_index_info(raw, nullptr, &sigma, &n_ks, file_ks, nullptr, nullptr), "kmer_index::load");
+            const std::uint32_t want[] = {std::uint32_t(ks)...};
+            bool same = sigma == traits::size && n_ks == sizeof...(ks);
+            for (std::uint32_t i = 0; same && i < n_ks; ++i) same = file_ks[i] == want[i];
+            if (!same) throw std::invalid_argument("kmer_index::load: the image was built for another alphabet or other ks");
+            return out;
         }
 
         // kmer_index.hpp:498-502

@@ -114,6 +114,21 @@ int main()
         auto r = index.search(longq).to_vector();
         CHECK(r.size() >= 1 && r.front() == 100);
     }
+    // save / load round trip of the flattened image
+    {
+        auto text = generate_sequence<dna4>(12, 80000);
+        auto index = kmer::make_kmer_index<7, 9>(text);
+        std::vector<dna4> q(text.begin() + 321, text.begin() + 321 + 16);
+        auto before = index.search(q).to_vector();
+        index.save("/tmp/kmx_host_api_test.img");
+        auto loaded = kmer::kmer_index<dna4, std::uint32_t, 7, 9>::load("/tmp/kmx_host_api_test.img");
+        CHECK(loaded.search(q).to_vector() == before);
+        CHECK(before == naive(text, q));
+        bool threw = false;
+        try { (void)kmer::kmer_index<dna4, std::uint32_t, 7, 10>::load("/tmp/kmx_host_api_test.img"); } catch (const std::invalid_argument&) { threw = true; }
+        CHECK(threw);
+        std::remove("/tmp/kmx_host_api_test.img");
+    }
     if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
     std::printf("host api ok\n");
     return 0;
