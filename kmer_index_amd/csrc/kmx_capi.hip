@@ -76,11 +76,12 @@ struct HostBuf {
 };
 
 enum KernelId {
-    K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK, K_COUNT
+    K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK,
+    K_PREFIX_SORT_SMALL, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_lookup", "k_scan(reduce+spine+down)", "k_partition", "k_fill", "k_validate", "k_compact",
-    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back"};
+    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small"};
 
 struct Stats {
     bool enabled = false;
@@ -587,6 +588,9 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     if (r->n_stitch)
         timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
 
+    if (r->n_prefix)
+        timed(ix, K_PREFIX_SORT_SMALL, s, [&] { kmx::launch_prefix_sort_small(s, dix, qo, d, r->n_prefix, hit_off, out); });
+
     if (r->n_prefix && max_runs > 1 && prefix_elems > 0) {
         // merge the per-key runs of every PREFIX slice into one ascending list
         const uint64_t np = r->n_prefix;
@@ -706,7 +710,7 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
             HIP_TRY(hipMemcpy(r->h_mask_base.p, r->aux.p, r->nq * 8, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(r->h_cand_count.p, r->c0.p, r->nq * 4, hipMemcpyDeviceToHost));
             HIP_TRY(hipMemcpy(r->h_cand_src.p, r->src.p, r->nq * 8, hipMemcpyDeviceToHost));
-            for (uint64_t i = 0; i < r->nq; ++i) r->h_cand_src.as<uint64_t>()[i] &= ~(uint64_t(1) << 63);   // internal flag
+            for (uint64_t i = 0; i < r->nq; ++i) r->h_cand_src.as<uint64_t>()[i] &= ~(uint64_t(3) << 62);   // internal flags
         }
         if (r->n_mask_words) HIP_TRY(hipMemcpy(r->h_mask_words.p, r->mask_words.p, r->n_mask_words * 8, hipMemcpyDeviceToHost));
         r->host_masks_valid = true;

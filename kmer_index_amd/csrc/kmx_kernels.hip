@@ -32,6 +32,10 @@ namespace kmx {
 // Flag in QueryDesc::src: the query is not a plain bucket copy (STITCH / PREFIX): k_fill
 // serves PREFIX slot by slot and leaves STITCH to k_compact.
 #define SRC_SLOW (uint64_t(1) << 63)
+// additionally set for PREFIX queries: k_fill copies their slice on its fast path, only the (rare)
+// last-kmer positions behind the slice take the per-slot path
+#define SRC_PREFIX (uint64_t(1) << 62)
+#define SRC_FLAGS (SRC_SLOW | SRC_PREFIX)
 
 // ---------------------------------------------------------------------------
 // small device helpers
@@ -437,8 +441,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     }
     if (my_prefix) {
         loc = atomicAdd(&bc.n_prefix, 1u);
-        atomicAdd(&bc.pelems, (unsigned long long)(cnt - __popcll(aux)));
-        atomicMax(&bc.max_runs, c0);
+        const uint32_t plen = cnt - uint32_t(__popcll(aux));
+        if (c0 > KMX_PSORT_MAX_RUNS || plen > KMX_PSORT_CAP) {   // large: global merge passes
+            atomicAdd(&bc.pelems, (unsigned long long)plen);
+            atomicMax(&bc.max_runs, c0);
+        }
     }
     if (q < nq && status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
     if (q < nq && status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     locs[it] = loc;
     locw[it] = loc_words;
     if (q < nq) {
-        d.src[q] = (kind == KMX_KIND_STITCH || kind == KMX_KIND_PREFIX) ? (src | SRC_SLOW) : src;
+        d.src[q] = kind == KMX_KIND_STITCH ? (src | SRC_SLOW) : (kind == KMX_KIND_PREFIX ? (src | SRC_FLAGS) : src);
         d.cnt[q] = cnt;
         d.kind[q] = kind;
         d.status[q] = status;
@@ -508,7 +515,7 @@ __device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const 
     const uint32_t lane = lane_id();
     const uint32_t sigma = ix->sigma;
     const uint32_t c0 = d.c0[q];
-    const uint64_t src = d.src[q] & ~SRC_SLOW;
+    const uint64_t src = d.src[q] & ~SRC_FLAGS;
     uint64_t* __restrict__ words = mask_words + d.aux[q];
     const uint32_t n_words = c0 / 64 + 1;                              // compressed_bitset.hpp:23
     const uint64_t b = qoff[q];
@@ -629,7 +636,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         const uint32_t q = have ? d.stitch_list[i] : 0u;
         // one round of independent loads per group
         const uint32_t c0 = have ? d.c0[q] : 0u;
-        const uint64_t src = have ? (d.src[q] & ~SRC_SLOW) : 0;
+        const uint64_t src = have ? (d.src[q] & ~SRC_FLAGS) : 0;
         const uint64_t p1 = have ? d.p1[q] : ~uint64_t(0);
         const uint64_t p1src = have ? d.key[q] : 0;
         uint64_t* __restrict__ words = mask_words + (have ? d.aux[q] : 0);
@@ -860,8 +867,26 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : (E <= 16 ? 6 : 4))) void 
         const uint64_t sv = d.src[q];
         // non-short-circuit on purpose: sv takes part so that its load is issued with the other two
         if ((e > s) & (e > base) & (s < tile_end) & (sv != ~uint64_t(0))) {
-            const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
-            word[slot] = (sv & SRC_SLOW) ? rec_t(SLOW | rec_t(q - qa)) : rec_t(sv + (base + slot - s) + (TILE - slot));
+            if (!(sv & SRC_SLOW)) {
+                const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
+                word[slot] = rec_t(sv + (base + slot - s) + (TILE - slot));
+            } else if (sv & SRC_PREFIX) {
+                // [s, s + len): the contiguous slice of every k-mer with this prefix -> plain copy;
+                // [s + len, e): last-kmer positions (kmer_index.hpp:90-112) -> per-slot path
+                const uint64_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+                const uint64_t mid = s + len;
+                if (len && mid > base) {
+                    const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
+                    word[slot] = rec_t((sv & ~SRC_FLAGS) + (base + slot - s) + (TILE - slot));
+                }
+                if (e > mid && mid < tile_end) {
+                    const uint32_t slot = mid > base ? uint32_t(mid - base) : 0u;
+                    word[slot] = rec_t(SLOW | rec_t(q - qa));
+                }
+            } else {
+                const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
+                word[slot] = rec_t(SLOW | rec_t(q - qa));              // STITCH: written by k_compact
+            }
         }
     }
     __syncthreads();
@@ -916,7 +941,7 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : (E <= 16 ? 6 : 4))) void 
         const uint64_t idx = base + slot - hit_off[q];
         const uint64_t tmask = d.aux[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(tmask));
-        if (idx < len) return arena[(d.src[q] & ~SRC_SLOW) + idx];
+        if (idx < len) return arena[(d.src[q] & ~SRC_FLAGS) + idx];
         uint32_t t = uint32_t(idx - len);                               // t-th smallest position = t-th highest bit
         uint64_t mm = tmask;
         int bit = 63 - __clzll(mm);
@@ -997,7 +1022,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_compact(const uint32_t* __restric
         const uint32_t q = d.stitch_list[i];
         if (d.cnt[q] == 0) continue;
         const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q] & ~SRC_SLOW;
+        const uint64_t src = d.src[q] & ~SRC_FLAGS;
         const uint64_t* __restrict__ words = mask_words + d.aux[q];
         uint64_t o = hit_off[q];
         const uint32_t n_words = c0 / 64 + 1;
@@ -1028,7 +1053,56 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t 
     const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
     if (i >= n_prefix) return;
     const uint32_t q = d.prefix_list[i];
-    plen[i] = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    plen[i] = (d.c0[q] > KMX_PSORT_MAX_RUNS || len > KMX_PSORT_CAP) ? len : 0u;   // small ones: k_prefix_sort_small
+}
+
+// PREFIX queries with few runs and a short slice: one wave sorts the slice that k_fill copied.  The
+// slice is the concatenation of R <= 16 ascending runs (one per key of the prefix range); a position's
+// final rank is the sum over the runs of "how many of this run are smaller" — one multi-way pass of
+// binary searches in LDS, which is the std::sort of kmer_index_result.hpp:258 for this query.
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexDev* __restrict__ ix,
+                                                                 const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                                 uint64_t n_prefix,
+                                                                 const uint64_t* __restrict__ hit_off,
+                                                                 uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t buf[KMX_BLOCK / KMX_WAVE][KMX_PSORT_CAP];
+    __shared__ uint32_t bnd[KMX_BLOCK / KMX_WAVE][KMX_PSORT_MAX_RUNS + 1];
+    const uint32_t lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    for (uint64_t i = wave; i < n_prefix; i += n_waves) {
+        const uint32_t q = d.prefix_list[i];
+        const uint32_t R = d.c0[q];
+        const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+        if (R > KMX_PSORT_MAX_RUNS || len > KMX_PSORT_CAP || R < 2 || len < 2) continue;   // wave-uniform
+        const uint64_t m = qoff[q + 1] - qoff[q];
+        const KmxPlanEntry pe = load_plan(ix, m);
+        const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
+        if (lane <= R) bnd[wv][lane] = offs[lane] - offs[0];
+        uint32_t* __restrict__ seg = out + hit_off[q];
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][t] = seg[t];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) {
+            const uint32_t x = buf[wv][t];
+            uint32_t pos = 0;
+            for (uint32_t r = 0; r < R; ++r) {
+                const uint32_t lo0 = bnd[wv][r], hi0 = bnd[wv][r + 1];
+                if (t >= lo0 && t < hi0) { pos += t - lo0; continue; }   // own run: elements before me
+                uint32_t lo = lo0, hi = hi0;                             // lower_bound of x in run r (no ties across runs)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if (buf[wv][mid] < x) lo = mid + 1; else hi = mid;
+                }
+                pos += lo - lo0;
+            }
+            seg[pos] = x;
+        }
+        __builtin_amdgcn_wave_barrier();                                 // buf/bnd are reused by the next query
+    }
 }
 
 __global__ __launch_bounds__(KMX_BLOCK) void k_merge_pass(const KmxIndexDev* __restrict__ ix,
@@ -1178,6 +1252,13 @@ void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, ui
 void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen)
 {
     hipLaunchKernelGGL(k_prefix_len, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, plen);
+}
+
+void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+                              const uint64_t* hit_off, uint32_t* out)
+{
+    unsigned int blocks = (unsigned int)std::min<uint64_t>((n_prefix + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_prefix_sort_small, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, out);
 }
 
 void launch_merge_pass(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,

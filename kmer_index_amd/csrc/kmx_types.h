@@ -62,6 +62,11 @@ struct KmxIndexDev {
     KmxElemDev elems[KMX_MAX_KS];
 };
 
+// PREFIX queries whose slice has at most KMX_PSORT_MAX_RUNS per-key runs and KMX_PSORT_CAP positions are
+// sorted in LDS by one wave (k_prefix_sort_small); larger ones go through the global merge passes.
+#define KMX_PSORT_MAX_RUNS 16
+#define KMX_PSORT_CAP 2048
+
 // Counter block written by the lookup kernel and read back once per batch.
 enum {
     KMX_CTR_EXACT = 0,
@@ -69,8 +74,8 @@ enum {
     KMX_CTR_PREFIX = 2,
     KMX_CTR_ERROR = 3,
     KMX_CTR_MASK_WORDS = 4,   // bump allocator for STITCH mask words
-    KMX_CTR_PREFIX_ELEMS = 5, // sum of PREFIX slice lengths
-    KMX_CTR_MAX_RUNS = 6,     // max number of runs of any PREFIX query
+    KMX_CTR_PREFIX_ELEMS = 5, // sum of the slice lengths of the LARGE PREFIX queries (global merge passes)
+    KMX_CTR_MAX_RUNS = 6,     // max number of runs of any LARGE PREFIX query
     KMX_CTR_TOTAL_HITS = 7,   // written by the scan
     KMX_CTR_NONE = 8,         // valid queries without a hit
     KMX_CTR_PREFIX_TOTAL = 9, // total of the scan over PREFIX slice lengths
