@@ -77,11 +77,11 @@ struct HostBuf {
 
 enum KernelId {
     K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK,
-    K_PREFIX_SORT_SMALL, K_COUNT
+    K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_lookup", "k_scan(reduce+spine+down)", "k_partition", "k_fill", "k_validate", "k_compact",
-    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small"};
+    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block"};
 
 struct Stats {
     bool enabled = false;
@@ -556,7 +556,8 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     r->n_stitch = r->h_ctr[KMX_CTR_STITCH];
-    r->n_prefix = r->h_ctr[KMX_CTR_PREFIX];
+    const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
+    r->n_prefix = n_prefix_small + n_prefix_big;
     r->n_error = r->h_ctr[KMX_CTR_ERROR];
     r->n_none = r->h_ctr[KMX_CTR_NONE];
     r->n_mask_words = r->h_ctr[KMX_CTR_MASK_WORDS];
@@ -588,17 +589,22 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     if (r->n_stitch)
         timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
 
-    if (r->n_prefix)
-        timed(ix, K_PREFIX_SORT_SMALL, s, [&] { kmx::launch_prefix_sort_small(s, dix, qo, d, r->n_prefix, hit_off, out); });
+    // PREFIX work list: small queries from the front of prefix_list, the others from its back
+    kmx::QueryDesc d_big = d;
+    d_big.prefix_list = d.prefix_list + (nq - n_prefix_big);
+    if (n_prefix_small)
+        timed(ix, K_PREFIX_SORT_SMALL, s, [&] { kmx::launch_prefix_sort_small(s, dix, qo, d, n_prefix_small, hit_off, out); });
+    if (n_prefix_big)
+        timed(ix, K_PREFIX_SORT_BLOCK, s, [&] { kmx::launch_prefix_sort_block(s, d_big, n_prefix_big, hit_off, out); });
 
-    if (r->n_prefix && max_runs > 1 && prefix_elems > 0) {
-        // merge the per-key runs of every PREFIX slice into one ascending list
-        const uint64_t np = r->n_prefix;
+    if (n_prefix_big && max_runs > 1 && prefix_elems > 0) {
+        // slices beyond the block sort's capacity: merge the per-key runs in global memory
+        const uint64_t np = n_prefix_big;
         HIP_TRY(r->plen.ensure(np * 4));
         HIP_TRY(r->poff.ensure((np + 1) * 8));
         HIP_TRY(r->ptmp.ensure(prefix_elems * 4));
         HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(np), kmx::scan_blocks(nq)) * 8));
-        timed(ix, K_PREFIX_LEN, s, [&] { kmx::launch_prefix_len(s, d, np, r->plen.as<uint32_t>()); });
+        timed(ix, K_PREFIX_LEN, s, [&] { kmx::launch_prefix_len(s, d_big, np, r->plen.as<uint32_t>()); });
         timed(ix, K_SCAN, s, [&] {
             kmx::launch_scan(s, r->plen.as<uint32_t>(), np, r->bsum.as<uint64_t>(), r->poff.as<uint64_t>(), ctr + KMX_CTR_PREFIX_TOTAL);
         });
@@ -607,14 +613,14 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         int src_is_out = 1;
         for (uint32_t p = 0; p < passes; ++p) {
             timed(ix, K_MERGE_PASS, s, [&] {
-                kmx::launch_merge_pass(s, dix, qr, qo, d, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out,
+                kmx::launch_merge_pass(s, dix, qr, qo, d_big, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out,
                                        r->ptmp.as<uint32_t>(), p, src_is_out);
             });
             src_is_out = !src_is_out;
         }
         if (!src_is_out)
             timed(ix, K_COPY_BACK, s, [&] {
-                kmx::launch_prefix_copy_back(s, d, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out, r->ptmp.as<uint32_t>());
+                kmx::launch_prefix_copy_back(s, d_big, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out, r->ptmp.as<uint32_t>());
             });
     }
     HIP_TRY(hipGetLastError());

@@ -160,10 +160,10 @@ __device__ __forceinline__ bool rank_hash(const uint8_t* __restrict__ q, uint32_
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_prefix, n_error, n_none;
+    unsigned int n_stitch, n_prefix, n_prefix_big, n_error, n_none;
     unsigned long long words, pelems;
     unsigned int max_runs;
-    unsigned int base_stitch, base_prefix;
+    unsigned int base_stitch, base_prefix, base_prefix_big;
     unsigned long long base_words;
 };
 
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_prefix = bc.n_error = bc.n_none = 0;
+        bc.n_stitch = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = 0;
         bc.words = bc.pelems = 0;
         bc.max_runs = 0;
     }
@@ -440,11 +440,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         loc_words = atomicAdd(&bc.words, my_words);
     }
     if (my_prefix) {
-        loc = atomicAdd(&bc.n_prefix, 1u);
         const uint32_t plen = cnt - uint32_t(__popcll(aux));
-        if (c0 > KMX_PSORT_MAX_RUNS || plen > KMX_PSORT_CAP) {   // large: global merge passes
-            atomicAdd(&bc.pelems, (unsigned long long)plen);
-            atomicMax(&bc.max_runs, c0);
+        if (c0 <= KMX_PSORT_MAX_RUNS && plen <= KMX_PSORT_CAP) {
+            loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
+        } else {
+            loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
+            if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: global merge passes
+                atomicAdd(&bc.pelems, (unsigned long long)plen);
+                atomicMax(&bc.max_runs, c0);
+            }
         }
     }
     if (q < nq && status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
@@ -475,10 +479,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
             bc.base_words = atomicAdd(&ctr[KMX_CTR_MASK_WORDS], bc.words);
         }
-        if (bc.n_prefix) {
-            bc.base_prefix = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX], (unsigned long long)bc.n_prefix);
-            atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
-            atomicMax(&ctr[KMX_CTR_MAX_RUNS], (unsigned long long)bc.max_runs);
+        if (bc.n_prefix) bc.base_prefix = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX], (unsigned long long)bc.n_prefix);
+        if (bc.n_prefix_big) {
+            bc.base_prefix_big = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX_BIG], (unsigned long long)bc.n_prefix_big);
+            if (bc.pelems) atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
+            if (bc.max_runs) atomicMax(&ctr[KMX_CTR_MAX_RUNS], (unsigned long long)bc.max_runs);
         }
         if (bc.n_error) atomicAdd(&ctr[KMX_CTR_ERROR], (unsigned long long)bc.n_error);
         if (bc.n_none) atomicAdd(&ctr[KMX_CTR_NONE], (unsigned long long)bc.n_none);
@@ -491,7 +496,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
             d.stitch_list[bc.base_stitch + locs[it]] = uint32_t(q);
         } else if (kinds[it] == KMX_KIND_PREFIX) {
-            d.prefix_list[bc.base_prefix + locs[it]] = uint32_t(q);
+            if (locs[it] & 0x80000000u) d.prefix_list[nq - 1 - (bc.base_prefix_big + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
+            else d.prefix_list[bc.base_prefix + locs[it]] = uint32_t(q);
         }
     }
 }
@@ -1052,9 +1058,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t 
 {
     const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
     if (i >= n_prefix) return;
-    const uint32_t q = d.prefix_list[i];
+    const uint32_t q = d.prefix_list[i];   // (the launcher passes the list region it wants walked)
     const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-    plen[i] = (d.c0[q] > KMX_PSORT_MAX_RUNS || len > KMX_PSORT_CAP) ? len : 0u;   // small ones: k_prefix_sort_small
+    plen[i] = len > KMX_PSORT_BLOCK_CAP ? len : 0u;   // the others: k_prefix_sort_small / k_prefix_sort_block
 }
 
 // PREFIX queries with few runs and a short slice: one wave sorts the slice that k_fill copied.  The
@@ -1252,6 +1258,56 @@ void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, ui
 void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen)
 {
     hipLaunchKernelGGL(k_prefix_len, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, plen);
+}
+
+
+// PREFIX slices that are too long or have too many runs for k_prefix_sort_small but fit 128 KB of
+// LDS: one 1024-thread block per query, bitonic sort of the slice padded to a power of two.
+#define KMX_PSB_THREADS 1024
+__global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc d, uint64_t n_prefix,
+                                                                        const uint64_t* __restrict__ hit_off,
+                                                                        uint32_t* __restrict__ out)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
+        const uint32_t q = d.prefix_list[i];
+        const uint32_t R = d.c0[q];
+        const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+        const bool small = R <= KMX_PSORT_MAX_RUNS && len <= KMX_PSORT_CAP;
+        if (small || len > KMX_PSORT_BLOCK_CAP || R < 2 || len < 2) continue;           // block-uniform
+        uint32_t n2 = 1;
+        while (n2 < len) n2 <<= 1;
+        uint32_t* __restrict__ seg = out + hit_off[q];
+        for (uint32_t t = tid; t < n2; t += KMX_PSB_THREADS) sbuf[t] = t < len ? seg[t] : 0xFFFFFFFFu;
+        __syncthreads();
+        for (uint32_t size = 2; size <= n2; size <<= 1) {
+            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+                for (uint32_t t = tid; t < n2 / 2; t += KMX_PSB_THREADS) {
+                    const uint32_t lo = 2 * t - (t & (stride - 1));                      // pair (lo, lo + stride)
+                    const uint32_t hi = lo + stride;
+                    const bool up = (lo & size) == 0;
+                    const uint32_t a = sbuf[lo], b = sbuf[hi];
+                    if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
+                }
+                __syncthreads();
+            }
+        }
+        for (uint32_t t = tid; t < len; t += KMX_PSB_THREADS) seg[t] = sbuf[t];
+        __syncthreads();
+    }
+}
+
+void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off, uint32_t* out)
+{
+    static bool attr_set = false;
+    const size_t lds = size_t(KMX_PSORT_BLOCK_CAP) * 4;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prefix_sort_block), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        attr_set = true;
+    }
+    unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
+    hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1), dim3(KMX_PSB_THREADS), lds, s, d, n_prefix, hit_off, out);
 }
 
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,

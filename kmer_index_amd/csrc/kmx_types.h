@@ -66,6 +66,9 @@ struct KmxIndexDev {
 // sorted in LDS by one wave (k_prefix_sort_small); larger ones go through the global merge passes.
 #define KMX_PSORT_MAX_RUNS 16
 #define KMX_PSORT_CAP 2048
+// ... up to KMX_PSORT_BLOCK_CAP positions (any number of runs) by one 1024-thread block (bitonic sort in
+// 128 KB of LDS, k_prefix_sort_block); beyond that the global merge passes.
+#define KMX_PSORT_BLOCK_CAP 32768
 
 // Counter block written by the lookup kernel and read back once per batch.
 enum {
@@ -79,5 +82,6 @@ enum {
     KMX_CTR_TOTAL_HITS = 7,   // written by the scan
     KMX_CTR_NONE = 8,         // valid queries without a hit
     KMX_CTR_PREFIX_TOTAL = 9, // total of the scan over PREFIX slice lengths
+    KMX_CTR_PREFIX_BIG = 11,  // PREFIX queries that are not 'small' (listed from the BACK of prefix_list)
     KMX_CTR_COUNT = 16
 };

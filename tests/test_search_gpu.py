@@ -289,3 +289,26 @@ def test_large_k_sort_based_flatten_and_rec64(engine, orc):
     ho, pos, st, kd = idx.search(q, off).host()
     o_off, o_pos, _, _ = orc.Index(text, 4, [6]).search_batch(q, off, n_threads=8)
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+
+
+def test_prefix_sort_all_size_classes(engine, orc):
+    """m < k slices of every class: few runs / short (wave-level LDS rank pass), mid-size or many runs (block-level
+    bitonic sort in LDS), and beyond 32 K positions (global merge passes) — all equal the oracle."""
+    text = synth.ranks(606, 600_000, 4)
+    idx = engine.Index(text, 4, [10])
+    oidx = orc.Index(text, 4, [10])
+    qs = []
+    for m, cnt in ((9, 40), (8, 40), (7, 30), (6, 20), (5, 10), (4, 6), (3, 4), (2, 2)):     # 4 .. 65536 runs; 2 .. 37 K hits
+        for t in range(cnt):
+            s0 = (t * 7919 + m * 104729) % (text.size - m)
+            qs.append(text[s0:s0 + m].copy())
+    qs += [text[text.size - m:].copy() for m in (9, 7, 4)]                                      # with last-kmer positions
+    qranks, qoff = pack(qs)
+    idx.stats_enable(True)
+    r = idx.search(qranks, qoff)
+    ho, pos, st, kd = r.host()
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+    assert (kd == engine.KIND_PREFIX).all()
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    k = idx.stats()
+    assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_merge_pass"]["launches"]
