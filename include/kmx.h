@@ -75,7 +75,9 @@ typedef struct kmx_options {
     uint32_t n_threads;    /* host threads for the per-k flatten (kmer_index ctor's n_threads, :481)    */
     uint32_t query_size_range; /* 0 = KMX_QUERY_SIZE_RANGE (extend_query_size_range, :498-502)          */
     uint32_t keep_host_arena;  /* keep a host copy of the position arena (kmx_index_arena_host)         */
-    uint32_t reserved[2];
+    uint32_t host_flatten;     /* 1 = build every element on host threads; 0 = on the device when the
+                                  key space allows (sigma^k <= 2^26), host otherwise                     */
+    uint32_t reserved[1];
 } kmx_options;
 
 /* kmx_search_batch flags */

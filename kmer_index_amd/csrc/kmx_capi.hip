@@ -199,6 +199,19 @@ kmx_status upload(kmx_index* ix, const T* host, size_t count, const T** dev_out)
     return KMX_OK;
 }
 
+// device scratch released at scope exit
+struct DeviceScratch {
+    std::vector<void*> ptrs;
+    ~DeviceScratch() { for (void* p : ptrs) (void)hipFree(p); }
+    template <typename T> hipError_t get(T** out, size_t count)
+    {
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, count * sizeof(T) + 64);
+        if (e == hipSuccess) { ptrs.push_back(p); *out = static_cast<T*>(p); }
+        return e;
+    }
+};
+
 kmx_status check_device()
 {
     int count = 0;
@@ -213,7 +226,7 @@ kmx_status check_device()
 // Uploads flattened element images and everything around them (tail, planner table, header).
 // Shared by kmx_index_build (images fresh from the flatten) and kmx_index_load (images from a file).
 static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const uint8_t* tail_kmax, uint64_t n, uint32_t sigma,
-                                 uint32_t range, int device, const kmx_options& o, kmx_index** out)
+                                 uint32_t range, int device, const kmx_options& o, kmx_index** out, void* prebuilt_arena)
 {
     auto* ix = new kmx_index();
     ix->device = device;
@@ -225,6 +238,8 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     for (auto& im : images) { ix->ks.push_back(im.k); kmax = std::max(kmax, im.k); }
     kmx_status st = KMX_OK;
     auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
+    for (auto& im : images)
+        if (im.d_offs_prebuilt) ix->allocs.push_back(const_cast<uint32_t*>(im.d_offs_prebuilt));   // device-built dense tables
 
     KmxIndexDev h{};
     h.n = n; h.sigma = sigma; h.n_ks = n_ks; h.kmax = kmax; h.range = range;
@@ -239,9 +254,11 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     uint64_t arena_elems = 0;
     for (auto& im : images) arena_elems += im.npos;
     {
-        void* p = nullptr;
-        hipError_t e = hipMalloc(&p, arena_elems * 4 + 64);   // padded: k_fill reads 16 bytes at any element
-        if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
+        void* p = prebuilt_arena;                             // device-built elements already sit in it
+        if (!p) {
+            hipError_t e = hipMalloc(&p, arena_elems * 4 + 64);   // padded: k_fill reads 16 bytes at any element
+            if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
+        }
         ix->allocs.push_back(p);
         ix->device_bytes += arena_elems * 4;
         h.arena = static_cast<const uint32_t*>(p);
@@ -268,10 +285,23 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos;
         ix->table_kinds.push_back(im.table_kind);
         ix->elem_sizes.push_back({im.offs.size(), im.slots.size(), im.ukeys.size()});
-        hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.npos * 4, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
-        if (o.keep_host_arena) ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.end());
-        if ((st = upload(ix, im.offs.data(), im.offs.size(), &el.offs)) != KMX_OK) return bail(st);
+        if (im.positions_on_device) {
+            if (o.keep_host_arena) {
+                const size_t at = ix->host_arena.size();
+                ix->host_arena.resize(at + im.npos);
+                hipError_t e = hipMemcpy(ix->host_arena.data() + at, h.arena + base, im.npos * 4, hipMemcpyDeviceToHost);
+                if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena download: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+            }
+        } else {
+            hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.npos * 4, hipMemcpyHostToDevice);
+            if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+            if (o.keep_host_arena) ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.end());
+        }
+        if (im.d_offs_prebuilt) {
+            el.offs = im.d_offs_prebuilt;                       // (owned by ix->allocs since the top of this function)
+            ix->device_bytes += (im.n_keys + 1) * 4;
+            ix->elem_sizes.back().n_offs = im.n_keys + 1;
+        } else if ((st = upload(ix, im.offs.data(), im.offs.size(), &el.offs)) != KMX_OK) return bail(st);
         if (im.table_kind == KMX_TABLE_OPEN) {
             if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
             if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
@@ -377,10 +407,90 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     HIP_TRY(hipSetDevice(device));
 
-    // flatten every element on host threads (the constructor's thread pool, kmer_index.hpp:485-492)
+    // letters must be ranks of the alphabet (the reference's alphabet_t cannot hold anything else)
+    {
+        uint32_t mx = 0;
+        for (uint64_t i = 0; i < n; ++i) mx = ranks[i] > mx ? ranks[i] : mx;
+        if (mx >= sigma) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: the text holds a letter outside the alphabet");
+    }
+
     std::vector<kmx::ElemImage> images(n_ks);
+    std::vector<char> on_device(n_ks, 0);
+
+    // 1. elements whose key space fits a histogram are built on the device (k_build_*, k_bucket_sort_*)
+    uint64_t arena_elems = 0;
+    for (uint32_t i = 0; i < n_ks; ++i) arena_elems += n - ks[i] + 1;
+    void* arena = nullptr;
+    {
+        hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
+        if (e != hipSuccess) return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e));
+    }
+    DeviceScratch scratch;
+    const uint64_t DEVICE_BUILD_MAX_KEYS = uint64_t(1) << 26;
+    uint64_t max_keys = 0;
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i]));
+        if (!o.host_flatten && nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
+    }
+    if (max_keys) {
+        uint8_t* d_text = nullptr; uint32_t* d_hist = nullptr; uint64_t* d_scr = nullptr; uint64_t* d_bsum = nullptr; uint32_t* d_cursor = nullptr;
+        unsigned int* d_max = nullptr; unsigned long long* d_total = nullptr;
+        hipError_t e = scratch.get(&d_text, n);
+        if (e == hipSuccess) e = scratch.get(&d_hist, max_keys);
+        if (e == hipSuccess) e = scratch.get(&d_scr, max_keys + 1);
+        if (e == hipSuccess) e = scratch.get(&d_bsum, kmx::scan_blocks(max_keys));
+        if (e == hipSuccess) e = scratch.get(&d_cursor, max_keys);
+        if (e == hipSuccess) e = scratch.get(&d_max, 4);
+        if (e == hipSuccess) e = scratch.get(&d_total, 2);
+        if (e == hipSuccess) e = hipMemcpy(d_text, ranks, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(arena); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("device build scratch: ") + hipGetErrorString(e)); }
+        uint64_t base = 0;
+        for (uint32_t i = 0; i < n_ks; ++i) {
+            const uint64_t npos = n - ks[i] + 1;
+            if (on_device[i]) {
+                const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i]));
+                uint32_t* d_offs = nullptr;
+                e = hipMalloc(reinterpret_cast<void**>(&d_offs), (nk + 1) * 4 + 64);
+                if (e != hipSuccess) { (void)hipFree(arena); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("offs: ") + hipGetErrorString(e)); }
+                uint32_t* d_pos = static_cast<uint32_t*>(arena) + base;
+                kmx::launch_build_element(nullptr, d_text, n, ks[i], sigma, nk, d_hist, d_scr, d_bsum, d_offs, d_cursor, d_pos, d_max, d_total);
+                unsigned int max_bucket = 0;
+                e = hipMemcpy(&max_bucket, d_max, sizeof max_bucket, hipMemcpyDeviceToHost);      // also synchronises
+                if (e == hipSuccess && max_bucket > KMX_PSORT_CAP && max_bucket <= KMX_PSORT_BLOCK_CAP) {
+                    kmx::launch_bucket_sort_block(nullptr, d_offs, nk, d_pos);
+                    e = hipDeviceSynchronize();
+                }
+                if (e != hipSuccess) { (void)hipFree(d_offs); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
+                if (max_bucket > KMX_PSORT_BLOCK_CAP) {
+                    // a bucket too large for the LDS sorts (heavily repetitive text): this element goes to the host flatten
+                    (void)hipFree(d_offs);
+                    on_device[i] = 0;
+                } else {
+                    kmx::ElemImage& im = images[i];
+                    im.k = ks[i]; im.n_keys = nk; im.npos = npos; im.positions_on_device = true;
+                    im.table_kind = kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind);
+                    if (im.table_kind == KMX_TABLE_DENSE) {
+                        im.d_offs_prebuilt = d_offs;                                             // the dense table itself
+                    } else {
+                        // open addressing requested: distinct keys / compact offsets / slots from the downloaded offsets
+                        std::vector<uint32_t> start(nk + 1);
+                        e = hipMemcpy(start.data(), d_offs, (nk + 1) * 4, hipMemcpyDeviceToHost);
+                        (void)hipFree(d_offs);
+                        if (e != hipSuccess) { (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("offs download: ") + hipGetErrorString(e)); }
+                        im.offs.push_back(0);
+                        for (uint64_t j = 0; j < nk; ++j)
+                            if (start[j + 1] != start[j]) { im.ukeys.push_back(j); im.offs.push_back(start[j + 1]); }
+                        kmx::build_slots(im);
+                    }
+                }
+            }
+            base += npos;
+        }
+    }
+
+    // 2. the others on host threads (the constructor's thread pool, kmer_index.hpp:485-492)
     std::vector<std::string> errs(n_ks);
-    std::vector<char> oks(n_ks, 0);
+    std::vector<char> oks(n_ks, 1);
     {
         uint32_t T = std::max<uint32_t>(1, std::min<uint32_t>(o.n_threads ? o.n_threads : std::thread::hardware_concurrency(), n_ks));
         std::vector<std::thread> threads;
@@ -390,15 +500,19 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
                 for (;;) {
                     uint32_t i = next.fetch_add(1);
                     if (i >= n_ks) return;
-                    oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i]);
+                    if (!on_device[i]) oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i]);
                 }
             });
         for (auto& t : threads) t.join();
     }
     for (uint32_t i = 0; i < n_ks; ++i)
-        if (!oks[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]);
+        if (!oks[i]) {
+            (void)hipFree(arena);
+            for (auto& im : images) if (im.d_offs_prebuilt) (void)hipFree(const_cast<uint32_t*>(im.d_offs_prebuilt));
+            return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]);
+        }
 
-    return install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out);
+    return install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena);
 }
 
 void kmx_index_free(kmx_index* ix)
@@ -893,5 +1007,5 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
     int device = o.device;
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     HIP_TRY(hipSetDevice(device));
-    return install_images_impl(images, tail.data(), fh.n, fh.sigma, o.query_size_range ? o.query_size_range : fh.range, device, o, out);
+    return install_images_impl(images, tail.data(), fh.n, fh.sigma, o.query_size_range ? o.query_size_range : fh.range, device, o, out, nullptr);
 }

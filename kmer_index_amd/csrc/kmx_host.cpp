@@ -107,7 +107,7 @@ static uint32_t ceil_log2_u64(uint64_t v)
     return l;
 }
 
-static void build_slots(ElemImage& im)
+void build_slots(ElemImage& im)
 {
     uint64_t u = im.ukeys.size();
     im.log2cap = std::max<uint32_t>(4, ceil_log2_u64(2 * std::max<uint64_t>(u, 1)));   // load <= 0.5
@@ -118,6 +118,13 @@ static void build_slots(ElemImage& im)
         while (im.slots[s].cnt != 0) s = (s + 1) & (cap - 1);   // linear probing
         im.slots[s] = KmxSlot{im.ukeys[i], im.offs[i], im.offs[i + 1] - im.offs[i]};
     }
+}
+
+uint32_t resolve_table_kind(uint32_t sigma, uint32_t k, uint64_t n, uint32_t requested)
+{
+    if (requested != KMX_TABLE_AUTO) return requested;
+    const uint64_t n_keys = fast_pow(sigma, uint8_t(k)), npos = n - k + 1, HIST_MAX = uint64_t(1) << 30;
+    return (n_keys <= 4 * npos && n_keys <= HIST_MAX) ? KMX_TABLE_DENSE : KMX_TABLE_OPEN;
 }
 
 bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t k, uint32_t table_kind,

@@ -30,12 +30,20 @@ struct ElemImage {
     std::vector<uint32_t> offs;        // dense: n_keys + 1; open: ukeys.size() + 1
     std::vector<uint64_t> ukeys;       // open only
     std::vector<KmxSlot> slots;        // open only
+    // built on the device (kmx_capi.hip): positions already sit in the arena, dense offs too
+    bool positions_on_device = false;
+    const uint32_t* d_offs_prebuilt = nullptr;
 };
 
 // Builds the image of one element — the work of kmer_index_element::create
 // (kmer_index.hpp:154-179).  Returns false and sets err on invalid parameters.
 bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t k, uint32_t table_kind,
                      ElemImage& out, std::string& err);
+
+// AUTO -> DENSE when sigma^k <= 4 (n-k+1) (and the key space fits a histogram), else OPEN.
+uint32_t resolve_table_kind(uint32_t sigma, uint32_t k, uint64_t n, uint32_t requested);
+// open-addressing slots from sorted distinct keys + offsets (im.ukeys, im.offs)
+void build_slots(ElemImage& im);
 
 // static_assert(k > 0 and k < 64 / log2(sigma)) of kmer_index.hpp:42-43.
 bool k_is_valid(uint32_t sigma, uint32_t k);

@@ -1310,6 +1310,152 @@ void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_pref
     hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1), dim3(KMX_PSB_THREADS), lds, s, d, n_prefix, hit_off, out);
 }
 
+// ---------------------------------------------------------------------------
+// Index construction on the device — the work of kmer_index_element::create
+// (kmer_index.hpp:154-179) for key spaces that fit a histogram:
+//   k_build_hist    rank-hash of every k-mer (Horner, :56-73), histogram by key
+//   (scan)          bucket offsets = exclusive scan of the histogram = the dense table offs[]
+//   k_build_scatter positions into their buckets through per-key cursors (arrival order)
+//   k_bucket_sort_* every bucket ascending — the order push_back yields at :160-167
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t kmer_hash_at(const uint8_t* __restrict__ text, uint64_t i, uint32_t k, uint32_t sigma)
+{
+    uint64_t h = 0;
+    for (uint32_t j = 0; j < k; ++j) h = h * sigma + text[i + j];
+    return h;
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_hist(const uint8_t* __restrict__ text, uint64_t npos, uint32_t k,
+                                                          uint32_t sigma, uint32_t* __restrict__ hist)
+{
+    const uint64_t stride = uint64_t(gridDim.x) * KMX_BLOCK;
+    for (uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x; i < npos; i += stride)
+        atomicAdd(&hist[kmer_hash_at(text, i, k, sigma)], 1u);
+}
+
+// offs64 (exclusive scan of hist, n_keys + 1 entries) -> offs32 and the scatter cursors; largest bucket
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_offsets(const uint64_t* __restrict__ offs64, uint64_t n_keys,
+                                                             uint32_t* __restrict__ offs32, uint32_t* __restrict__ cursor,
+                                                             unsigned int* __restrict__ max_bucket)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    uint32_t sz = 0;
+    if (i <= n_keys) {
+        const uint32_t o = uint32_t(offs64[i]);
+        offs32[i] = o;
+        if (i < n_keys) { cursor[i] = o; sz = uint32_t(offs64[i + 1]) - o; }
+    }
+    for (int off = 32; off > 0; off >>= 1) sz = max(sz, uint32_t(__shfl_xor(int(sz), off)));
+    if (lane_id() == 0 && sz) atomicMax(max_bucket, sz);
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_scatter(const uint8_t* __restrict__ text, uint64_t npos, uint32_t k,
+                                                             uint32_t sigma, uint32_t* __restrict__ cursor,
+                                                             uint32_t* __restrict__ positions)
+{
+    const uint64_t stride = uint64_t(gridDim.x) * KMX_BLOCK;
+    for (uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x; i < npos; i += stride)
+        positions[atomicAdd(&cursor[kmer_hash_at(text, i, k, sigma)], 1u)] = uint32_t(i);
+}
+
+// bitonic sort of n2 (power of two) LDS words by `nthreads` cooperating threads; `sync` separates the stages
+template <typename Sync>
+__device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_t tid, uint32_t nthreads, Sync sync)
+{
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = sbuf[lo], b = sbuf[hi];
+                if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
+            }
+            sync();
+        }
+    }
+}
+
+// one wave per bucket of at most KMX_PSORT_CAP positions
+__global__ __launch_bounds__(KMX_BLOCK) void k_bucket_sort_wave(const uint32_t* __restrict__ offs, uint64_t n_keys,
+                                                                uint32_t* __restrict__ positions)
+{
+    __shared__ uint32_t buf[KMX_BLOCK / KMX_WAVE][KMX_PSORT_CAP];
+    const uint32_t lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (uint64_t h = wave; h < n_keys; h += n_waves) {
+        const uint32_t lo = offs[h], len = offs[h + 1] - lo;
+        if (len < 2 || len > KMX_PSORT_CAP) continue;                    // wave-uniform
+        uint32_t n2 = 2;
+        while (n2 < len) n2 <<= 1;
+        uint32_t* __restrict__ seg = positions + lo;
+        for (uint32_t t = lane; t < n2; t += KMX_WAVE) buf[wv][t] = t < len ? seg[t] : 0xFFFFFFFFu;
+        wsync();
+        bitonic_lds(buf[wv], n2, lane, KMX_WAVE, wsync);
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][t];
+        wsync();
+    }
+}
+
+// one 1024-thread block per bucket of KMX_PSORT_CAP+1 .. KMX_PSORT_BLOCK_CAP positions
+__global__ __launch_bounds__(1024) void k_bucket_sort_block(const uint32_t* __restrict__ offs, uint64_t n_keys,
+                                                            uint32_t* __restrict__ positions)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t h = blockIdx.x; h < n_keys; h += gridDim.x) {
+        const uint32_t lo = offs[h], len = offs[h + 1] - lo;
+        if (len <= KMX_PSORT_CAP || len > KMX_PSORT_BLOCK_CAP) continue; // block-uniform
+        uint32_t n2 = 2;
+        while (n2 < len) n2 <<= 1;
+        uint32_t* __restrict__ seg = positions + lo;
+        for (uint32_t t = tid; t < n2; t += 1024) sbuf[t] = t < len ? seg[t] : 0xFFFFFFFFu;
+        __syncthreads();
+        bitonic_lds(sbuf, n2, tid, 1024u, [] { __syncthreads(); });
+        for (uint32_t t = tid; t < len; t += 1024) seg[t] = sbuf[t];
+        __syncthreads();
+    }
+}
+
+// Builds one element's positions (grouped by key, ascending inside a group) and its dense offsets on the
+// device.  scratch_u64 needs n_keys + 1 entries, cursor n_keys, bsum scan_blocks(n_keys) entries.  Returns
+// the size of the largest bucket through *d_max_bucket (device word, read back by the caller).
+void launch_build_element(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
+                          uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_offs, uint32_t* d_cursor,
+                          uint32_t* d_positions, unsigned int* d_max_bucket, unsigned long long* d_total)
+{
+    const uint64_t npos = n - k + 1;
+    const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks_for(npos, KMX_BLOCK), 256 * 64);
+    hipMemsetAsync(d_hist, 0, n_keys * sizeof(uint32_t), s);
+    hipMemsetAsync(d_max_bucket, 0, sizeof(unsigned int), s);
+    hipLaunchKernelGGL(k_build_hist, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_hist);
+    launch_scan(s, d_hist, n_keys, d_bsum, d_scratch_u64, d_total);
+    hipLaunchKernelGGL(k_build_offsets, dim3(blocks_for(n_keys + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_scratch_u64, n_keys, d_offs,
+                       d_cursor, d_max_bucket);
+    hipLaunchKernelGGL(k_build_scatter, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_cursor, d_positions);
+    const unsigned int wblocks = (unsigned int)std::min<uint64_t>((n_keys + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_bucket_sort_wave, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_positions);
+}
+
+// second stage for buckets beyond the wave sort's capacity (call when max bucket > KMX_PSORT_CAP)
+void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_keys, uint32_t* d_positions)
+{
+    static bool attr_set = false;
+    const size_t lds = size_t(KMX_PSORT_BLOCK_CAP) * 4;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort_block), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
+        attr_set = true;
+    }
+    const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_keys, 256 * 4);
+    hipLaunchKernelGGL(k_bucket_sort_block, dim3(blocks ? blocks : 1), dim3(1024), lds, s, d_offs, n_keys, d_positions);
+}
+
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
                               const uint64_t* hit_off, uint32_t* out)
 {

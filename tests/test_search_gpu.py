@@ -312,3 +312,34 @@ def test_prefix_sort_all_size_classes(engine, orc):
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
     k = idx.stats()
     assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_merge_pass"]["launches"]
+
+
+@pytest.mark.parametrize("table", ["open", "dense"])
+def test_device_built_index_equals_host_flatten(engine, orc, table):
+    """Index construction on the device (k_build_*, k_bucket_sort_*) yields the same arena as the host flatten
+    (positions grouped by rank-hash, ascending inside a bucket) and the same answers."""
+    text = synth.ranks(515, 500_000, 4)
+    ks = [4, 9, 12]
+    tk = engine.TABLE_OPEN if table == "open" else engine.TABLE_DENSE
+    dev = engine.Index(text, 4, ks, table=tk, keep_host_arena=True)
+    host = engine.Index(text, 4, ks, table=tk, keep_host_arena=True, host_flatten=True)
+    assert np.array_equal(dev.arena_host(), host.arena_host())
+    assert dev.info()["tables"] == host.info()["tables"] == [tk] * 3
+    qranks, qoff = make_queries(text, 4, [2, 4, 6, 9, 12, 13, 18, 21, 24], 30, seed=12)
+    a = dev.search(qranks, qoff).host()
+    b = host.search(qranks, qoff).host()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    o_off, o_pos, _, _ = orc.Index(text, 4, ks).search_batch(qranks, qoff, n_threads=4)
+    assert np.array_equal(a[0], o_off) and np.array_equal(a[1], o_pos)
+    # a text with a bucket beyond the LDS sorts' capacity takes the host fallback for that element
+    skew = np.zeros(100_000, np.uint8)
+    skew[::3] = 1
+    d2 = engine.Index(skew, 4, [6, 3], keep_host_arena=True)
+    h2 = engine.Index(skew, 4, [6, 3], keep_host_arena=True, host_flatten=True)
+    assert np.array_equal(d2.arena_host(), h2.arena_host())
+    # ranks outside the alphabet are refused
+    bad = text.copy()
+    bad[1234] = 7
+    with pytest.raises(engine.KmxError):
+        engine.Index(bad, 4, [5])
