@@ -133,7 +133,7 @@ struct kmx_index {
     KmxIndexDev* d_index = nullptr;     // device copy of the header
     const uint32_t* d_arena = nullptr;  // the position arena (also in the header; passed to kernels directly)
     unsigned long long* d_dbg = nullptr; // KMX_CHECKED violation records
-    struct ElemSizes { size_t n_offs, n_slots, n_ukeys; };
+    struct ElemSizes { size_t n_offs, n_slots, n_ukeys, n_aoffs; };
     std::vector<ElemSizes> elem_sizes;   // element array lengths (for kmx_index_save)
     std::vector<uint8_t> tail;           // last kmax letters of the text
     KmxIndexDev h_header{};              // host copy of the device header (holds device pointers)
@@ -238,8 +238,10 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     for (auto& im : images) { ix->ks.push_back(im.k); kmax = std::max(kmax, im.k); }
     kmx_status st = KMX_OK;
     auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
-    for (auto& im : images)
-        if (im.d_offs_prebuilt) ix->allocs.push_back(const_cast<uint32_t*>(im.d_offs_prebuilt));   // device-built dense tables
+    for (auto& im : images) {   // device-built dense tables
+        if (im.d_offs_prebuilt) ix->allocs.push_back(const_cast<uint32_t*>(im.d_offs_prebuilt));
+        if (im.d_atab_prebuilt) ix->allocs.push_back(const_cast<uint32_t*>(im.d_atab_prebuilt));
+    }
 
     KmxIndexDev h{};
     h.n = n; h.sigma = sigma; h.n_ks = n_ks; h.kmax = kmax; h.range = range;
@@ -252,7 +254,11 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     }
     // arena = every element's positions back to back
     uint64_t arena_elems = 0;
-    for (auto& im : images) arena_elems += im.npos;
+    for (auto& im : images) {
+        if (!im.region) im.region = im.npos;
+        if (im.region > im.npos) arena_elems = (arena_elems + 31) & ~uint64_t(31);   // an aligned copy needs a line-aligned base
+        arena_elems += im.region;
+    }
     {
         void* p = prebuilt_arena;                             // device-built elements already sit in it
         if (!p) {
@@ -282,31 +288,41 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         auto& im = images[i];
         KmxElemDev& el = h.elems[i];
         el.k = im.k; el.table_kind = im.table_kind; el.log2cap = im.log2cap; el.n_ukeys = uint32_t(im.ukeys.size());
-        el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos;
+        if (im.region > im.npos) base = (base + 31) & ~uint64_t(31);
+        el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos; el.region = im.region; el.atab = nullptr;
         ix->table_kinds.push_back(im.table_kind);
-        ix->elem_sizes.push_back({im.offs.size(), im.slots.size(), im.ukeys.size()});
+        ix->elem_sizes.push_back({im.offs.size(), im.slots.size(), im.ukeys.size(),
+                                  (im.d_atab_prebuilt || (im.table_kind == KMX_TABLE_DENSE && !im.atab.empty())) ? size_t(im.n_keys + 1) : size_t(0)});
         if (im.positions_on_device) {
             if (o.keep_host_arena) {
-                const size_t at = ix->host_arena.size();
-                ix->host_arena.resize(at + im.npos);
-                hipError_t e = hipMemcpy(ix->host_arena.data() + at, h.arena + base, im.npos * 4, hipMemcpyDeviceToHost);
+                ix->host_arena.resize(base + im.region);
+                hipError_t e = hipMemcpy(ix->host_arena.data() + base, h.arena + base, im.region * 4, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena download: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
             }
         } else {
-            hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.npos * 4, hipMemcpyHostToDevice);
+            hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.region * 4, hipMemcpyHostToDevice);
             if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
-            if (o.keep_host_arena) ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.end());
+            if (o.keep_host_arena) {
+                ix->host_arena.resize(base, 0);
+                ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.begin() + im.region);
+            }
         }
         if (im.d_offs_prebuilt) {
             el.offs = im.d_offs_prebuilt;                       // (owned by ix->allocs since the top of this function)
             ix->device_bytes += (im.n_keys + 1) * 4;
             ix->elem_sizes.back().n_offs = im.n_keys + 1;
         } else if ((st = upload(ix, im.offs.data(), im.offs.size(), &el.offs)) != KMX_OK) return bail(st);
+        if (im.d_atab_prebuilt) {
+            el.atab = im.d_atab_prebuilt;
+            ix->device_bytes += (im.n_keys + 1) * 4;
+        } else if (im.table_kind == KMX_TABLE_DENSE && !im.atab.empty()) {
+            if ((st = upload(ix, im.atab.data(), im.atab.size(), &el.atab)) != KMX_OK) return bail(st);
+        }
         if (im.table_kind == KMX_TABLE_OPEN) {
             if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
             if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
         }
-        base += im.npos;
+        base += im.region;
         im = kmx::ElemImage();   // release host memory early
     }
     ix->tail.assign(tail_kmax, tail_kmax + kmax);
@@ -418,73 +434,64 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     std::vector<char> on_device(n_ks, 0);
 
     // 1. elements whose key space fits a histogram are built on the device (k_build_*, k_bucket_sort_*)
-    uint64_t arena_elems = 0;
-    for (uint32_t i = 0; i < n_ks; ++i) arena_elems += n - ks[i] + 1;
-    void* arena = nullptr;
-    {
-        hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
-        if (e != hipSuccess) return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e));
-    }
+    const bool aligned_copy = !o.no_aligned_copy && !(getenv("KMX_ALIGNED") && atoi(getenv("KMX_ALIGNED")) == 0);
+    void* arena = nullptr;   // allocated by install_images_impl once every element's region is known
     DeviceScratch scratch;
     const uint64_t DEVICE_BUILD_MAX_KEYS = uint64_t(1) << 26;
+    auto up32 = [](uint64_t v) { return (v + 31) & ~uint64_t(31); };
     uint64_t max_keys = 0;
     for (uint32_t i = 0; i < n_ks; ++i) {
         const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i]));
         if (!o.host_flatten && nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
     }
+    // per device-built element, filled by phase 1
+    struct DevElem { uint32_t* d_offs = nullptr; uint32_t* d_aoffs = nullptr; uint32_t* d_atab = nullptr; uint32_t max_bucket = 0; uint64_t a0 = 0; };
+    std::vector<DevElem> dev(n_ks);
+    auto free_dev = [&] { for (auto& de : dev) { if (de.d_offs) (void)hipFree(de.d_offs); if (de.d_aoffs) (void)hipFree(de.d_aoffs); if (de.d_atab) (void)hipFree(de.d_atab); de = DevElem(); } };
+    uint8_t* d_text = nullptr; uint32_t* d_hist = nullptr; uint64_t* d_scr = nullptr; uint64_t* d_bsum = nullptr; uint32_t* d_cursor = nullptr;
+    unsigned int* d_info = nullptr; unsigned long long* d_total = nullptr;
     if (max_keys) {
-        uint8_t* d_text = nullptr; uint32_t* d_hist = nullptr; uint64_t* d_scr = nullptr; uint64_t* d_bsum = nullptr; uint32_t* d_cursor = nullptr;
-        unsigned int* d_max = nullptr; unsigned long long* d_total = nullptr;
         hipError_t e = scratch.get(&d_text, n);
         if (e == hipSuccess) e = scratch.get(&d_hist, max_keys);
         if (e == hipSuccess) e = scratch.get(&d_scr, max_keys + 1);
         if (e == hipSuccess) e = scratch.get(&d_bsum, kmx::scan_blocks(max_keys));
         if (e == hipSuccess) e = scratch.get(&d_cursor, max_keys);
-        if (e == hipSuccess) e = scratch.get(&d_max, 4);
+        if (e == hipSuccess) e = scratch.get(&d_info, 4);
         if (e == hipSuccess) e = scratch.get(&d_total, 2);
         if (e == hipSuccess) e = hipMemcpy(d_text, ranks, n, hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(arena); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("device build scratch: ") + hipGetErrorString(e)); }
-        uint64_t base = 0;
+        if (e != hipSuccess) return fail(KMX_ERR_OUT_OF_MEMORY, std::string("device build scratch: ") + hipGetErrorString(e));
+        // phase 1: histogram, offsets (= the dense table), sizes
         for (uint32_t i = 0; i < n_ks; ++i) {
-            const uint64_t npos = n - ks[i] + 1;
-            if (on_device[i]) {
-                const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i]));
-                uint32_t* d_offs = nullptr;
-                e = hipMalloc(reinterpret_cast<void**>(&d_offs), (nk + 1) * 4 + 64);
-                if (e != hipSuccess) { (void)hipFree(arena); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("offs: ") + hipGetErrorString(e)); }
-                uint32_t* d_pos = static_cast<uint32_t*>(arena) + base;
-                kmx::launch_build_element(nullptr, d_text, n, ks[i], sigma, nk, d_hist, d_scr, d_bsum, d_offs, d_cursor, d_pos, d_max, d_total);
-                unsigned int max_bucket = 0;
-                e = hipMemcpy(&max_bucket, d_max, sizeof max_bucket, hipMemcpyDeviceToHost);      // also synchronises
-                if (e == hipSuccess && max_bucket > KMX_PSORT_CAP && max_bucket <= KMX_PSORT_BLOCK_CAP) {
-                    kmx::launch_bucket_sort_block(nullptr, d_offs, nk, d_pos);
-                    e = hipDeviceSynchronize();
-                }
-                if (e != hipSuccess) { (void)hipFree(d_offs); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
-                if (max_bucket > KMX_PSORT_BLOCK_CAP) {
-                    // a bucket too large for the LDS sorts (heavily repetitive text): this element goes to the host flatten
-                    (void)hipFree(d_offs);
-                    on_device[i] = 0;
-                } else {
-                    kmx::ElemImage& im = images[i];
-                    im.k = ks[i]; im.n_keys = nk; im.npos = npos; im.positions_on_device = true;
-                    im.table_kind = kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind);
-                    if (im.table_kind == KMX_TABLE_DENSE) {
-                        im.d_offs_prebuilt = d_offs;                                             // the dense table itself
-                    } else {
-                        // open addressing requested: distinct keys / compact offsets / slots from the downloaded offsets
-                        std::vector<uint32_t> start(nk + 1);
-                        e = hipMemcpy(start.data(), d_offs, (nk + 1) * 4, hipMemcpyDeviceToHost);
-                        (void)hipFree(d_offs);
-                        if (e != hipSuccess) { (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("offs download: ") + hipGetErrorString(e)); }
-                        im.offs.push_back(0);
-                        for (uint64_t j = 0; j < nk; ++j)
-                            if (start[j + 1] != start[j]) { im.ukeys.push_back(j); im.offs.push_back(start[j + 1]); }
-                        kmx::build_slots(im);
-                    }
-                }
+            if (!on_device[i]) continue;
+            const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i])), npos = n - ks[i] + 1;
+            e = hipMalloc(reinterpret_cast<void**>(&dev[i].d_offs), (nk + 1) * 4 + 64);
+            if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("offs: ") + hipGetErrorString(e)); }
+            kmx::launch_build_phase1(nullptr, d_text, n, ks[i], sigma, nk, d_hist, d_scr, d_bsum, dev[i].d_offs, d_cursor, d_info, d_total);
+            unsigned int info[4] = {0, 0, 0, 0};
+            unsigned long long totals[2] = {0, 0};
+            e = hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost);                      // also synchronises
+            if (e == hipSuccess) e = hipMemcpy(totals, d_total, sizeof totals, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
+            kmx::ElemImage& im = images[i];
+            if (info[0] > KMX_PSORT_BLOCK_CAP) {
+                // a bucket too large for the LDS sorts (heavily repetitive text): this element goes to the host flatten
+                (void)hipFree(dev[i].d_offs);
+                dev[i] = DevElem();
+                on_device[i] = 0;
+                continue;
             }
-            base += npos;
+            dev[i].max_bucket = info[0];
+            im.k = ks[i]; im.n_keys = nk; im.npos = npos; im.positions_on_device = true;
+            im.table_kind = kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind);
+            im.region = npos;
+            const uint64_t present = info[1], padded_total = totals[1];
+            if (aligned_copy && present && npos >= 32 * present && up32(npos) + padded_total < 0xFFFFFFFFull) {
+                dev[i].a0 = up32(npos);
+                im.region = dev[i].a0 + padded_total;
+                e = hipMalloc(reinterpret_cast<void**>(&dev[i].d_aoffs), nk * 4 + 64);
+                if (e == hipSuccess && im.table_kind == KMX_TABLE_DENSE) e = hipMalloc(reinterpret_cast<void**>(&dev[i].d_atab), (nk + 1) * 4 + 64);
+                if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("aoffs: ") + hipGetErrorString(e)); }
+            }
         }
     }
 
@@ -500,17 +507,63 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
                 for (;;) {
                     uint32_t i = next.fetch_add(1);
                     if (i >= n_ks) return;
-                    if (!on_device[i]) oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i]);
+                    if (!on_device[i]) oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i], aligned_copy);
                 }
             });
         for (auto& t : threads) t.join();
     }
     for (uint32_t i = 0; i < n_ks; ++i)
-        if (!oks[i]) {
-            (void)hipFree(arena);
-            for (auto& im : images) if (im.d_offs_prebuilt) (void)hipFree(const_cast<uint32_t*>(im.d_offs_prebuilt));
-            return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]);
+        if (!oks[i]) { free_dev(); return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]); }
+
+    // 3. every region is known now: allocate the arena, then phase 2 of the device-built elements
+    uint64_t arena_elems = 0;
+    std::vector<uint64_t> bases(n_ks);
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        if (!images[i].region) images[i].region = images[i].npos;
+        if (images[i].region > images[i].npos) arena_elems = up32(arena_elems);
+        bases[i] = arena_elems;
+        arena_elems += images[i].region;
+    }
+    {
+        hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
+        if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); }
+    }
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        if (!on_device[i]) continue;
+        kmx::ElemImage& im = images[i];
+        uint32_t* d_region = static_cast<uint32_t*>(arena) + bases[i];
+        kmx::launch_build_phase2(nullptr, d_text, n, ks[i], sigma, im.n_keys, dev[i].d_offs, d_hist, d_scr, d_bsum, d_cursor, d_info, d_total,
+                                 d_region, dev[i].d_aoffs, uint32_t(dev[i].a0), dev[i].max_bucket > KMX_PSORT_CAP, dev[i].d_atab, uint32_t(im.region));
+        hipError_t e = hipDeviceSynchronize();
+        if (e != hipSuccess) { free_dev(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
+        if (im.table_kind == KMX_TABLE_DENSE) {
+            im.d_offs_prebuilt = dev[i].d_offs;                      // the dense table itself
+            im.d_atab_prebuilt = dev[i].d_atab;
+            if (dev[i].d_aoffs) (void)hipFree(dev[i].d_aoffs);       // only needed to lay out the copy
+            dev[i] = DevElem();
+        } else {
+            // open addressing requested: distinct keys / compact offsets / slots from the downloaded offsets
+            std::vector<uint32_t> start(im.n_keys + 1), astart;
+            e = hipMemcpy(start.data(), dev[i].d_offs, (im.n_keys + 1) * 4, hipMemcpyDeviceToHost);
+            if (e == hipSuccess && dev[i].d_aoffs) {
+                astart.resize(im.n_keys);
+                e = hipMemcpy(astart.data(), dev[i].d_aoffs, im.n_keys * 4, hipMemcpyDeviceToHost);
+            }
+            if (e != hipSuccess) { free_dev(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("offs download: ") + hipGetErrorString(e)); }
+            im.offs.push_back(0);
+            for (uint64_t j = 0; j < im.n_keys; ++j)
+                if (start[j + 1] != start[j]) {
+                    im.ukeys.push_back(j);
+                    im.offs.push_back(start[j + 1]);
+                    if (!astart.empty()) im.aoffs.push_back(astart[j]);
+                }
+            kmx::build_slots(im);
+            im.aoffs.clear();                                        // only the slots carry it for open tables
+            (void)hipFree(dev[i].d_offs);
+            if (dev[i].d_aoffs) (void)hipFree(dev[i].d_aoffs);
+            dev[i] = DevElem();
         }
+    }
 
     return install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena);
 }
@@ -863,7 +916,7 @@ namespace {
 
 struct FileHeader {
     char magic[8];          // "KMXIMG01"
-    uint32_t version;       // 1
+    uint32_t version;       // 2
     uint32_t sigma;
     uint64_t n;
     uint32_t n_ks;
@@ -874,7 +927,7 @@ struct FileHeader {
 };
 struct FileElem {
     uint32_t k, table_kind, log2cap, reserved;
-    uint64_t n_keys, npos, n_offs, n_slots, n_ukeys;
+    uint64_t n_keys, npos, n_offs, n_slots, n_ukeys, region, n_aoffs;
 };
 
 struct Mixer {                       // word-wise 64-bit checksum (order sensitive)
@@ -919,14 +972,14 @@ extern "C" kmx_status kmx_index_save(const kmx_index* ix, const char* path)
     const uint32_t n_ks = uint32_t(ix->ks.size());
     FileHeader fh{};
     memcpy(fh.magic, "KMXIMG01", 8);
-    fh.version = 1; fh.sigma = ix->sigma; fh.n = ix->n; fh.n_ks = n_ks; fh.range = ix->range; fh.kmax = ix->h_header.kmax;
+    fh.version = 2; fh.sigma = ix->sigma; fh.n = ix->n; fh.n_ks = n_ks; fh.range = ix->range; fh.kmax = ix->h_header.kmax;
     bool ok = fwrite(&fh, sizeof fh, 1, f) == 1;
     Mixer mx;
     std::vector<FileElem> fes(n_ks);
     for (uint32_t i = 0; i < n_ks; ++i) {
         const KmxElemDev& el = ix->h_header.elems[i];
         fes[i] = FileElem{el.k, el.table_kind, el.log2cap, 0, el.n_keys, el.npos, ix->elem_sizes[i].n_offs, ix->elem_sizes[i].n_slots,
-                          ix->elem_sizes[i].n_ukeys};
+                          ix->elem_sizes[i].n_ukeys, el.region, ix->elem_sizes[i].n_aoffs};
     }
     ok = ok && write_section(f, mx, fes.data(), fes.size() * sizeof(FileElem));
     ok = ok && write_section(f, mx, ix->tail.data(), ix->tail.size());
@@ -940,8 +993,9 @@ extern "C" kmx_status kmx_index_save(const kmx_index* ix, const char* path)
     kmx_status st = ok ? KMX_OK : fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_save: write failed");
     for (uint32_t i = 0; i < n_ks && st == KMX_OK; ++i) {
         const KmxElemDev& el = ix->h_header.elems[i];
-        st = dump(ix->d_arena + el.arena_base, el.npos * 4);
+        st = dump(ix->d_arena + el.arena_base, el.region * 4);
         if (st == KMX_OK) st = dump(el.offs, ix->elem_sizes[i].n_offs * 4);
+        if (st == KMX_OK) st = dump(el.atab, ix->elem_sizes[i].n_aoffs * 4);
         if (st == KMX_OK) st = dump(el.slots, ix->elem_sizes[i].n_slots * sizeof(KmxSlot));
         if (st == KMX_OK) st = dump(el.ukeys, ix->elem_sizes[i].n_ukeys * 8);
     }
@@ -967,7 +1021,7 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
     if (!f) return fail(KMX_ERR_INVALID_ARGUMENT, std::string("kmx_index_load: cannot open ") + path);
     struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
     FileHeader fh{};
-    if (fread(&fh, sizeof fh, 1, f) != 1 || memcmp(fh.magic, "KMXIMG01", 8) != 0 || fh.version != 1)
+    if (fread(&fh, sizeof fh, 1, f) != 1 || memcmp(fh.magic, "KMXIMG01", 8) != 0 || fh.version != 2)
         return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: not a kmx index image (bad magic / version)");
     if (fh.n_ks == 0 || fh.n_ks > KMX_MAX_KS || fh.kmax == 0 || fh.kmax > 63 || fh.n < fh.kmax || fh.n + fh.kmax - 1 >= 0xFFFFFFFFull ||
         fh.range == 0 || fh.range > 65535 * 9u)
@@ -980,7 +1034,8 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
         const bool dense = fe.table_kind == KMX_TABLE_DENSE, open = fe.table_kind == KMX_TABLE_OPEN;
         if (!kmx::k_is_valid(fh.sigma, fe.k) || fe.npos != fh.n - fe.k + 1 || fe.n_keys != kmx::fast_pow(fh.sigma, uint8_t(fe.k)) || !(dense || open) ||
             (dense && (fe.n_offs != fe.n_keys + 1 || fe.n_slots || fe.n_ukeys)) ||
-            (open && (fe.n_offs != fe.n_ukeys + 1 || fe.log2cap > 40 || fe.n_slots != (uint64_t(1) << fe.log2cap) || fe.n_ukeys > fe.npos)))
+            (open && (fe.n_offs != fe.n_ukeys + 1 || fe.log2cap > 40 || fe.n_slots != (uint64_t(1) << fe.log2cap) || fe.n_ukeys > fe.npos)) ||
+            fe.region < fe.npos || fe.region >= 0xFFFFFFFFull || (fe.n_aoffs != 0 && !(dense && fe.n_aoffs == fe.n_keys + 1 && fe.region > fe.npos)))
             return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: corrupt element table");
         kmax = std::max(kmax, fe.k);
     }
@@ -991,13 +1046,15 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
     for (uint32_t i = 0; i < fh.n_ks; ++i) {
         const FileElem& fe = fes[i];
         kmx::ElemImage& im = images[i];
-        im.k = fe.k; im.table_kind = fe.table_kind; im.log2cap = fe.log2cap; im.n_keys = fe.n_keys; im.npos = fe.npos;
+        im.k = fe.k; im.table_kind = fe.table_kind; im.log2cap = fe.log2cap; im.n_keys = fe.n_keys; im.npos = fe.npos; im.region = fe.region;
         try {
-            im.positions.resize(fe.npos); im.offs.resize(fe.n_offs); im.slots.resize(fe.n_slots); im.ukeys.resize(fe.n_ukeys);
+            im.positions.resize(fe.region); im.offs.resize(fe.n_offs); im.slots.resize(fe.n_slots); im.ukeys.resize(fe.n_ukeys);
+            im.atab.resize(fe.n_aoffs);
         } catch (const std::bad_alloc&) {
             return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_index_load: host allocation failed");
         }
-        if (!read_section(f, mx, im.positions.data(), fe.npos * 4) || !read_section(f, mx, im.offs.data(), fe.n_offs * 4) ||
+        if (!read_section(f, mx, im.positions.data(), fe.region * 4) || !read_section(f, mx, im.offs.data(), fe.n_offs * 4) ||
+            !read_section(f, mx, im.atab.data(), fe.n_aoffs * 4) ||
             !read_section(f, mx, im.slots.data(), fe.n_slots * sizeof(KmxSlot)) || !read_section(f, mx, im.ukeys.data(), fe.n_ukeys * 8))
             return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
     }

@@ -116,7 +116,8 @@ void build_slots(ElemImage& im)
     for (uint64_t i = 0; i < u; ++i) {
         uint64_t s = slot_hash(im.ukeys[i], im.log2cap);
         while (im.slots[s].cnt != 0) s = (s + 1) & (cap - 1);   // linear probing
-        im.slots[s] = KmxSlot{im.ukeys[i], im.offs[i], im.offs[i + 1] - im.offs[i]};
+        // off addresses the line-aligned copy when the element has one (exact lookups / stitch candidates read it)
+        im.slots[s] = KmxSlot{im.ukeys[i], im.aoffs.empty() ? im.offs[i] : im.aoffs[i], im.offs[i + 1] - im.offs[i]};
     }
 }
 
@@ -127,8 +128,38 @@ uint32_t resolve_table_kind(uint32_t sigma, uint32_t k, uint64_t n, uint32_t req
     return (n_keys <= 4 * npos && n_keys <= HIST_MAX) ? KMX_TABLE_DENSE : KMX_TABLE_OPEN;
 }
 
+void add_aligned_copy(ElemImage& im)
+{
+    const uint64_t n_groups = im.offs.size() - 1;
+    uint64_t present = 0;
+    for (uint64_t g = 0; g < n_groups; ++g) present += im.offs[g + 1] != im.offs[g];
+    im.region = im.npos;
+    im.aoffs.clear();
+    if (present == 0 || im.npos < 32 * present) return;          // short buckets: padding would cost more than it saves
+    auto up32 = [](uint64_t v) { return (v + 31) & ~uint64_t(31); };
+    uint64_t cur = up32(im.npos);
+    uint64_t end = cur;
+    for (uint64_t g = 0; g < n_groups; ++g) end += up32(im.offs[g + 1] - im.offs[g]);
+    if (end >= 0xFFFFFFFFull) return;
+    im.positions.resize(end, 0);
+    im.aoffs.resize(n_groups);
+    for (uint64_t g = 0; g < n_groups; ++g) {
+        const uint32_t a = im.offs[g], c = im.offs[g + 1] - a;
+        im.aoffs[g] = uint32_t(cur);
+        std::copy(im.positions.begin() + a, im.positions.begin() + a + c, im.positions.begin() + cur);
+        cur += up32(c);
+    }
+    im.region = end;
+    if (im.table_kind == KMX_TABLE_DENSE) {
+        im.atab.resize(n_groups + 1);
+        for (uint64_t g = 0; g < n_groups; ++g) im.atab[g] = ((im.aoffs[g] >> 5) << 5) | ((im.offs[g + 1] - im.offs[g]) & 31u);
+        im.atab[n_groups] = uint32_t(end >> 5) << 5;
+        im.aoffs.clear();
+    }
+}
+
 bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t k, uint32_t table_kind,
-                     ElemImage& im, std::string& err)
+                     ElemImage& im, std::string& err, bool aligned_copy)
 {
     if (!k_is_valid(sigma, k)) { err = "k must satisfy 0 < k < 64 / log2(sigma)"; return false; }
     if (n < k) { err = "text shorter than k"; return false; }
@@ -171,12 +202,15 @@ bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t 
             if (i + 1 >= im.npos) break;
             h = (h - uint64_t(ranks[i]) * top) * sigma + ranks[i + k];
         }
+        im.region = im.npos;
         if (table_kind == KMX_TABLE_DENSE) {
             im.offs.swap(start);
+            if (aligned_copy) add_aligned_copy(im);
         } else {
             im.offs.push_back(0);
             for (uint64_t j = 0; j < im.n_keys; ++j)
                 if (start[j + 1] != start[j]) { im.ukeys.push_back(j); im.offs.push_back(start[j + 1]); }
+            if (aligned_copy) add_aligned_copy(im);
             build_slots(im);
         }
     } else {
@@ -197,6 +231,8 @@ bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t 
                 im.offs.push_back(uint32_t(i + 1));
             }
         }
+        im.region = im.npos;
+        if (aligned_copy) add_aligned_copy(im);
         build_slots(im);
     }
     return true;

@@ -26,19 +26,25 @@ struct ElemImage {
     uint32_t log2cap = 0;
     uint64_t n_keys = 0;
     uint64_t npos = 0;
-    std::vector<uint32_t> positions;   // npos entries, grouped by hash
+    std::vector<uint32_t> positions;   // region entries: npos grouped by hash [+ the line-aligned copy of the groups]
+    std::vector<uint32_t> aoffs;       // aligned copy: start of every group (transient: feeds the open slots / atab)
+    std::vector<uint32_t> atab;        // dense: packed (start/32) << 5 | (count & 31), n_keys + 1 entries
+    uint64_t region = 0;               // npos, or the end of the aligned copy
     std::vector<uint32_t> offs;        // dense: n_keys + 1; open: ukeys.size() + 1
     std::vector<uint64_t> ukeys;       // open only
     std::vector<KmxSlot> slots;        // open only
     // built on the device (kmx_capi.hip): positions already sit in the arena, dense offs too
     bool positions_on_device = false;
     const uint32_t* d_offs_prebuilt = nullptr;
+    const uint32_t* d_atab_prebuilt = nullptr;
 };
 
 // Builds the image of one element — the work of kmer_index_element::create
 // (kmer_index.hpp:154-179).  Returns false and sets err on invalid parameters.
 bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t k, uint32_t table_kind,
-                     ElemImage& out, std::string& err);
+                     ElemImage& out, std::string& err, bool aligned_copy = true);
+// appends the 128-byte-aligned copy of the groups to im.positions (when the buckets are long enough)
+void add_aligned_copy(ElemImage& im);
 
 // AUTO -> DENSE when sigma^k <= 4 (n-k+1) (and the key space fits a histogram), else OPEN.
 uint32_t resolve_table_kind(uint32_t sigma, uint32_t k, uint64_t n, uint32_t requested);

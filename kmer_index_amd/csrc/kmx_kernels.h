@@ -44,9 +44,13 @@ void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, ui
                     const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out);
 void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen);
 // index construction on the device (see kmx_kernels.hip)
-void launch_build_element(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
-                          uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_offs, uint32_t* d_cursor,
-                          uint32_t* d_positions, unsigned int* d_max_bucket, unsigned long long* d_total);
+void launch_build_phase1(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
+                         uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_offs, uint32_t* d_cursor,
+                         unsigned int* d_info, unsigned long long* d_total);
+void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
+                         const uint32_t* d_offs, uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_cursor,
+                         unsigned int* d_info, unsigned long long* d_total, uint32_t* d_region, uint32_t* d_aoffs, uint32_t a0,
+                         bool block_sort, uint32_t* d_atab, uint32_t region_end);
 void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_keys, uint32_t* d_positions);
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
                               const uint64_t* hit_off, uint32_t* out);

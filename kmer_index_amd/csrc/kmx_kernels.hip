@@ -74,15 +74,29 @@ __device__ __forceinline__ uint64_t slot_hash_dev(uint64_t key, uint32_t log2cap
     return log2cap ? (key * 0x9E3779B97F4A7C15ull) >> (64 - log2cap) : 0;
 }
 
+// size of a group from two consecutive packed entries of KmxElemDev::atab
+__device__ __forceinline__ uint32_t atab_count(uint32_t e0, uint32_t e1)
+{
+    const uint32_t padded = (e1 & ~31u) - (e0 & ~31u), r = e0 & 31u;
+    return padded ? (r ? padded - 32u + r : padded) : 0u;
+}
+
 // at(hash) — kmer_index.hpp:76-84: the bucket of one rank-hash, or cnt == 0.
 __device__ __forceinline__ Run probe(const KmxElemDev* __restrict__ el, uint64_t h)
 {
     Run r;
     if (el->table_kind == KMX_TABLE_DENSE) {
+        if (el->atab) {                                       // the line-aligned copy of the bucket
+            const KMX_GLOBAL uint32_t* atab = as_global(el->atab);
+            const uint32_t e0 = atab[h], e1 = atab[h + 1];
+            r.src = el->arena_base + (e0 & ~31u);
+            r.cnt = atab_count(e0, e1);
+            return r;
+        }
         const KMX_GLOBAL uint32_t* offs = as_global(el->offs);
         uint32_t a = offs[h], b = offs[h + 1];
-        r.src = el->arena_base + a;
         r.cnt = b - a;
+        r.src = el->arena_base + a;
         return r;
     }
     const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);
@@ -247,8 +261,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             // first probe: dense -> offs[h], offs[h+1]; open -> the slot {key, off, cnt}; both as one 16-byte load
             const char* addr = reinterpret_cast<const char*>(dummy);
             if (done[it] && ok) {
-                if (el->table_kind == KMX_TABLE_DENSE) addr = reinterpret_cast<const char*>(el->offs + acc);
-                else addr = reinterpret_cast<const char*>(el->slots + slot_hash_dev(acc, el->log2cap));
+                if (el->table_kind == KMX_TABLE_DENSE) {
+                    addr = reinterpret_cast<const char*>((el->atab ? el->atab : el->offs) + acc);
+                } else {
+                    addr = reinterpret_cast<const char*>(el->slots + slot_hash_dev(acc, el->log2cap));
+                }
             }
             pr[it] = *(const KMX_GLOBAL u32x4_a1*)addr;
         }
@@ -266,8 +283,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             if (!rok[it]) {
                 status = KMX_Q_BAD_RANK;
             } else if (el->table_kind == KMX_TABLE_DENSE) {
-                src = el->arena_base + pr[it][0];
-                cnt = pr[it][1] - pr[it][0];
+                if (el->atab) { src = el->arena_base + (pr[it][0] & ~31u); cnt = atab_count(pr[it][0], pr[it][1]); }
+                else { src = el->arena_base + pr[it][0]; cnt = pr[it][1] - pr[it][0]; }
             } else {
                 // linear probing continues from the prefetched slot (at(hash), :76-84)
                 const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);
@@ -1423,24 +1440,95 @@ __global__ __launch_bounds__(1024) void k_bucket_sort_block(const uint32_t* __re
     }
 }
 
-// Builds one element's positions (grouped by key, ascending inside a group) and its dense offsets on the
-// device.  scratch_u64 needs n_keys + 1 entries, cursor n_keys, bsum scan_blocks(n_keys) entries.  Returns
-// the size of the largest bucket through *d_max_bucket (device word, read back by the caller).
-void launch_build_element(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
-                          uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_offs, uint32_t* d_cursor,
-                          uint32_t* d_positions, unsigned int* d_max_bucket, unsigned long long* d_total)
+void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_keys, uint32_t* d_positions);
+
+// padded[h] = bucket size rounded up to a 128-byte line (32 positions); also counts the non-empty buckets
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_padded(const uint32_t* __restrict__ offs, uint64_t n_keys,
+                                                            uint32_t* __restrict__ padded, unsigned int* __restrict__ present)
+{
+    const uint64_t h = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    uint32_t c = 0;
+    if (h < n_keys) {
+        c = offs[h + 1] - offs[h];
+        padded[h] = (c + 31u) & ~31u;
+    }
+    const uint64_t nz = __ballot(c != 0);
+    if (lane_id() == 0 && nz) atomicAdd(present, (unsigned int)__popcll(nz));
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_aoffs(const uint64_t* __restrict__ pscan, uint64_t n_keys, uint32_t a0,
+                                                           uint32_t* __restrict__ aoffs)
+{
+    const uint64_t h = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (h < n_keys) aoffs[h] = a0 + uint32_t(pscan[h]);
+}
+
+// dense table of the aligned copy: (start/32) << 5 | (count & 31); entry n_keys = end of the copy
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_atab(const uint32_t* __restrict__ offs, const uint32_t* __restrict__ aoffs,
+                                                          uint64_t n_keys, uint32_t end, uint32_t* __restrict__ atab)
+{
+    const uint64_t h = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (h < n_keys) atab[h] = (aoffs[h] & ~31u) | ((offs[h + 1] - offs[h]) & 31u);
+    else if (h == n_keys) atab[h] = end & ~31u;
+}
+
+// one wave per bucket: contiguous copy -> line-aligned copy (both inside the element's arena region)
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_aligned_copy(const uint32_t* __restrict__ offs,
+                                                                  const uint32_t* __restrict__ aoffs, uint64_t n_keys,
+                                                                  uint32_t* __restrict__ region)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    for (uint64_t h = wave; h < n_keys; h += n_waves) {
+        const uint32_t lo = offs[h], len = offs[h + 1] - lo, dst = aoffs[h];
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) region[dst + t] = region[lo + t];
+    }
+}
+
+// Phase 1 of the device build of one element: histogram of the rank-hashes, bucket offsets (= the dense
+// table), largest bucket, number of non-empty buckets and the size of the line-aligned copy.
+// info (device, 4 words): [0] max bucket, [1] non-empty buckets; d_total[0] = npos, d_total[1] = padded total.
+void launch_build_phase1(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
+                         uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_offs, uint32_t* d_cursor,
+                         unsigned int* d_info, unsigned long long* d_total)
 {
     const uint64_t npos = n - k + 1;
     const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks_for(npos, KMX_BLOCK), 256 * 64);
     hipMemsetAsync(d_hist, 0, n_keys * sizeof(uint32_t), s);
-    hipMemsetAsync(d_max_bucket, 0, sizeof(unsigned int), s);
+    hipMemsetAsync(d_info, 0, 4 * sizeof(unsigned int), s);
     hipLaunchKernelGGL(k_build_hist, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_hist);
     launch_scan(s, d_hist, n_keys, d_bsum, d_scratch_u64, d_total);
     hipLaunchKernelGGL(k_build_offsets, dim3(blocks_for(n_keys + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_scratch_u64, n_keys, d_offs,
-                       d_cursor, d_max_bucket);
-    hipLaunchKernelGGL(k_build_scatter, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_cursor, d_positions);
+                       d_cursor, d_info);
+    // size of the aligned copy (d_hist is free again: reuse it for the padded counts)
+    hipLaunchKernelGGL(k_build_padded, dim3(blocks_for(n_keys, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_hist, d_info + 1);
+    launch_scan(s, d_hist, n_keys, d_bsum, d_scratch_u64, d_total + 1);
+}
+
+// Phase 2 (after the arena exists): positions into their buckets, every bucket ascending, and
+// (d_aoffs != NULL) the line-aligned copy starting at element a0 of the region.  The scratch buffers are
+// shared between elements, so cursors and the scan of the padded counts are recomputed here.
+void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
+                         const uint32_t* d_offs, uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_cursor,
+                         unsigned int* d_info, unsigned long long* d_total, uint32_t* d_region, uint32_t* d_aoffs, uint32_t a0,
+                         bool block_sort, uint32_t* d_atab, uint32_t region_end)
+{
+    const uint64_t npos = n - k + 1;
+    const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks_for(npos, KMX_BLOCK), 256 * 64);
+    hipMemcpyAsync(d_cursor, d_offs, n_keys * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    hipLaunchKernelGGL(k_build_scatter, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_cursor, d_region);
     const unsigned int wblocks = (unsigned int)std::min<uint64_t>((n_keys + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_bucket_sort_wave, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_positions);
+    hipLaunchKernelGGL(k_bucket_sort_wave, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_region);
+    if (block_sort) launch_bucket_sort_block(s, d_offs, n_keys, d_region);
+    if (d_aoffs) {
+        hipLaunchKernelGGL(k_build_padded, dim3(blocks_for(n_keys, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_hist, d_info + 1);
+        launch_scan(s, d_hist, n_keys, d_bsum, d_scratch_u64, d_total + 1);
+        hipLaunchKernelGGL(k_build_aoffs, dim3(blocks_for(n_keys, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_scratch_u64, n_keys, a0, d_aoffs);
+        hipLaunchKernelGGL(k_build_aligned_copy, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, d_aoffs, n_keys, d_region);
+        if (d_atab)
+            hipLaunchKernelGGL(k_build_atab, dim3(blocks_for(n_keys + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_offs, d_aoffs, n_keys, region_end, d_atab);
+    }
 }
 
 // second stage for buckets beyond the wave sort's capacity (call when max bucket > KMX_PSORT_CAP)

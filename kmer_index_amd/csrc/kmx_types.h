@@ -18,6 +18,10 @@ struct KmxSlot {
 //   positions of all k-mers, grouped by rank-hash in ascending hash order and
 //   ascending inside a group (the order push_back produces at :160-167), stored
 //   in the shared arena at [arena_base, arena_base + npos);
+//   for elements with long buckets (>= 32 positions on average) a SECOND copy of the
+//   groups follows in which every group starts on a 128-byte line: exact lookups and
+//   stitch candidates read that copy (a 381-byte run then touches 3 lines, not 4 on
+//   average), prefix ranges keep using the contiguous copy;
 //   dense table : offs[h] .. offs[h+1] bound the group of hash h (n_offs = sigma^k + 1);
 //   open table  : ukeys[i] (ascending distinct hashes) with offs[i] .. offs[i+1],
 //                 plus KmxSlot slots[1 << log2cap] for O(1) exact probes.
@@ -29,9 +33,15 @@ struct KmxElemDev {
     uint64_t n_keys;       // sigma^k
     uint64_t arena_base;   // element index into the arena
     uint64_t npos;         // n - k + 1
-    const uint32_t* offs;  // group boundaries, relative to arena_base
+    const uint32_t* offs;  // group boundaries of the contiguous copy, relative to arena_base
     const KmxSlot* slots;  // open only
     const uint64_t* ukeys; // open only
+    const uint32_t* atab;  // dense + line-aligned copy: n_keys + 1 packed entries (start/32) << 5 | (count & 31) —
+                           // start of the group in that copy (relative to arena_base, a multiple of 32) and the low
+                           // bits of its size; the size itself is the padded difference to the next entry adjusted by
+                           // those bits, so an exact lookup reads 8 bytes of ONE 4-byte-per-key table.  Open tables
+                           // carry the aligned start in KmxSlot::off instead.  NULL: no aligned copy.
+    uint64_t region;       // elements this element occupies in the arena (contiguous copy [+ aligned copy])
 };
 
 // Planner entry for one query length m — what kmer_index::search consults at

@@ -35,7 +35,7 @@ class KmxError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_kind", C.c_uint32),
                 ("n_threads", C.c_uint32), ("query_size_range", C.c_uint32), ("keep_host_arena", C.c_uint32),
-                ("host_flatten", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("host_flatten", C.c_uint32), ("no_aligned_copy", C.c_uint32)]
 
 
 class KernelStat(C.Structure):
@@ -202,7 +202,7 @@ class Index:
     """kmx_index handle: the flattened kmer_index<alphabet_t, uint32_t, ks...> resident in HBM."""
 
     def __init__(self, ranks, sigma, ks, table=TABLE_AUTO, device=-1, n_threads=0, keep_host_arena=False,
-                 query_size_range=0, host_flatten=False):
+                 query_size_range=0, host_flatten=False, aligned_copy=True):
         ranks = np.ascontiguousarray(ranks, np.uint8)
         ks = np.ascontiguousarray(ks, np.uint32)
         self.ks = ks.tolist()
@@ -216,6 +216,7 @@ class Index:
         o.query_size_range = query_size_range
         o.keep_host_arena = int(keep_host_arena)
         o.host_flatten = int(host_flatten)
+        o.no_aligned_copy = int(not aligned_copy)
         self._h = C.c_void_p()
         _check(lib().kmx_index_build(ranks.ctypes.data, ranks.size, self.sigma, ks.ctypes.data, ks.size,
                                      C.byref(o), C.byref(self._h)))

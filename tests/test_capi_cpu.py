@@ -112,7 +112,7 @@ def test_index_load_rejects_bad_images_before_touching_the_device(engine, tmp_pa
     assert e.value.status == 1
     trunc = tmp_path / "trunc.kmx"
     import struct
-    trunc.write_bytes(b"KMXIMG01" + struct.pack("<IIQIIIIQ", 1, 4, 1000, 1, 10000, 5, 0, 0))
+    trunc.write_bytes(b"KMXIMG01" + struct.pack("<IIQIIIIQ", 2, 4, 1000, 1, 10000, 5, 0, 0))
     with pytest.raises(engine.KmxError) as e:
         engine.Index.load(str(trunc))
     assert e.value.status == 1 and "truncated" in str(e.value)
