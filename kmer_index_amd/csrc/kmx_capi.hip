@@ -159,6 +159,7 @@ struct kmx_result {
     // host mirrors
     HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src;
     bool host_valid = false, host_masks_valid = false;
+    bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
 
     void release()
     {
@@ -720,9 +721,22 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         });
     };
     scan_hits();
+    // Steady state (tile table and output buffer kept from an earlier batch): k_fill goes out right behind the
+    // scan, before the host knows the hit total — it reads the total from device memory and its grid is sized
+    // from what the buffers can hold.  Valid whenever the batch holds no STITCH query (their counts come later)
+    // and the total fits; both are checked after the read-back, and the regular path below redoes the fill if not.
+    // Only attempted when the previous batch on this handle had no STITCH query either.
+    const uint64_t spec_tiles = std::min<uint64_t>(tile_cap >= 2 ? tile_cap - 1 : 0, (r->out.cap / 4) / tile);
+    const bool spec_fill = !(flags & KMX_SEARCH_COUNT_ONLY) && !r->last_had_stitch && spec_tiles > 0 && spec_tiles < 0x7FFFFFFFull;
+    if (spec_fill)
+        timed(ix, K_FILL, s, [&] {
+            kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, r->hit_off.as<uint64_t>(), r->tile_q.as<uint32_t>(),
+                             ctr + KMX_CTR_TOTAL_HITS, spec_tiles, d, r->out.as<uint32_t>());
+        });
     HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     r->n_stitch = r->h_ctr[KMX_CTR_STITCH];
+    r->last_had_stitch = r->n_stitch != 0;
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
     r->n_prefix = n_prefix_small + n_prefix_big;
     r->n_error = r->h_ctr[KMX_CTR_ERROR];
@@ -750,9 +764,14 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->tile_q.ensure((n_tiles + 1) * 4));
     uint32_t* out = r->out.as<uint32_t>();
     const uint64_t* hit_off = r->hit_off.as<uint64_t>();
-    if (n_tiles + 1 > tile_cap)   // first batch / the table had to grow: the scan could not fill it
-        timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, tile, n_tiles, r->tile_q.as<uint32_t>()); });
-    timed(ix, K_FILL, s, [&] { kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, hit_off, r->tile_q.as<uint32_t>(), total, n_tiles, d, out); });
+    const bool spec_ok = spec_fill && r->n_stitch == 0 && n_tiles <= spec_tiles;   // the early k_fill already did the work
+    if (!spec_ok) {
+        if (n_tiles + 1 > tile_cap)   // first batch / the table had to grow: the scan could not fill it
+            timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, tile, n_tiles, r->tile_q.as<uint32_t>()); });
+        timed(ix, K_FILL, s, [&] {
+            kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, hit_off, r->tile_q.as<uint32_t>(), ctr + KMX_CTR_TOTAL_HITS, n_tiles, d, out);
+        });
+    }
     if (r->n_stitch)
         timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
 

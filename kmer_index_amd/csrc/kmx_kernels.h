@@ -39,7 +39,7 @@ void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* 
 uint64_t fill_tile(const FillVariant& v);
 void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q);
 void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
-                 const uint32_t* tile_q, uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out);
+                 const uint32_t* tile_q, const unsigned long long* total_dev, uint64_t n_tiles, const QueryDesc& d, uint32_t* out);
 void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,
                     const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out);
 void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen);

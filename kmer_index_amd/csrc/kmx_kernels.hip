@@ -862,10 +862,15 @@ template <int E, bool NT, typename rec_t>
 __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : (E <= 16 ? 6 : 4))) void k_fill(const KmxIndexDev* __restrict__ ix,
                                                     const uint32_t* __restrict__ arena,
                                                     const uint64_t* __restrict__ hit_off,
-                                                    const uint32_t* __restrict__ tile_q, uint64_t total,
+                                                    const uint32_t* __restrict__ tile_q,
+                                                    const unsigned long long* __restrict__ total_dev,
                                                     QueryDesc d, uint32_t* __restrict__ out)
 {
     constexpr int TILE = KMX_BLOCK * E;
+    // the hit total lives in device memory so that the kernel can be launched before the host has read it;
+    // the grid is then sized from an upper bound and surplus blocks leave here
+    const uint64_t total = *total_dev;
+    if (uint64_t(blockIdx.x) * TILE >= total) return;
     constexpr rec_t SLOW = RecTraits<rec_t>::SLOW;
     constexpr int VW = 16 / sizeof(rec_t);                     // words per 16-byte LDS access
     typedef rec_t recv_t __attribute__((ext_vector_type(VW)));
@@ -1235,7 +1240,7 @@ void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t 
 
 template <int E, bool NT>
 static void launch_fill_rec(hipStream_t s, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off, const uint32_t* tile_q,
-                            uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
+                            const unsigned long long* total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
 {
     if (rec32)
         hipLaunchKernelGGL((k_fill<E, NT, uint32_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
@@ -1244,7 +1249,7 @@ static void launch_fill_rec(hipStream_t s, bool rec32, const KmxIndexDev* ix, co
 }
 
 void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
-                 const uint32_t* tile_q, uint64_t total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
+                 const uint32_t* tile_q, const unsigned long long* total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
 {
 #define KMX_FILL_CASE(E_, NT_)                                                                         \
     if (v.e == E_ && v.nt == NT_) {                                                                    \
