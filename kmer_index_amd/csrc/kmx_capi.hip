@@ -277,7 +277,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     if (const char* fvs = getenv("KMX_FILL_VARIANT")) {
         // tuning knob: "<e>[n]", e.g. "8n", "16", "16n"
         int e = atoi(fvs);
-        if (e == 4 || e == 8 || e == 12 || e == 16 || e == 24 || e == 32) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'n') != nullptr};
+        if (e == 4 || e == 8 || e == 12 || e == 16) ix->fill_variant = kmx::FillVariant{e, strchr(fvs, 'n') != nullptr};
     }
     {
         void* p = nullptr;
@@ -708,7 +708,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     // speculative scan: already final when the batch holds no STITCH query
     // The downsweep also records the first query of every output tile (k_partition's job) when the
     // tile table kept from an earlier batch is large enough — the steady state.
-    const kmx::FillVariant fv = ix->fill_variant;
+    const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
     const uint64_t tile = kmx::fill_tile(fv);
     const uint64_t tile_cap = r->tile_q.cap / 4;            // entries available while the scan runs
     auto scan_hits = [&] {

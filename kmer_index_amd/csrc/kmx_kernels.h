@@ -36,6 +36,7 @@ struct FillVariant {
 };
 void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
                        unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q);
+FillVariant effective_fill_variant(const FillVariant& v, bool rec32);
 uint64_t fill_tile(const FillVariant& v);
 void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q);
 void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,

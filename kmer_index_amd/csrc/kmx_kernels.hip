@@ -859,7 +859,7 @@ struct RecTraits {
 // word" scan then hands every slot s its owner's word, and the element for s is
 //     arena[v - TILE + s].
 template <int E, bool NT, typename rec_t>
-__global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : (E <= 16 ? 6 : 4))) void k_fill(const KmxIndexDev* __restrict__ ix,
+__global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const KmxIndexDev* __restrict__ ix,
                                                     const uint32_t* __restrict__ arena,
                                                     const uint64_t* __restrict__ hit_off,
                                                     const uint32_t* __restrict__ tile_q,
@@ -1231,30 +1231,37 @@ void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* 
 }
 
 // fill variants, selected at run time (KMX_FILL_VARIANT, see kmx_capi.hip)
-uint64_t fill_tile(const FillVariant& v) { return uint64_t(KMX_BLOCK) * v.e; }
+uint64_t fill_tile(const FillVariant& v) { return uint64_t(KMX_BLOCK) * v.e; }   // of an effective variant
 
 void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q)
 {
     hipLaunchKernelGGL(k_partition, dim3(blocks_for(n_tiles + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, off, nq, tile, n_tiles, tile_q);
 }
 
-template <int E, bool NT>
-static void launch_fill_rec(hipStream_t s, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off, const uint32_t* tile_q,
-                            const unsigned long long* total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
+// The variant actually launched: 64-bit records (arenas >= 4 GiB) double the LDS per slot, so they always
+// use 2048-slot tiles.
+FillVariant effective_fill_variant(const FillVariant& v, bool rec32)
 {
-    if (rec32)
-        hipLaunchKernelGGL((k_fill<E, NT, uint32_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
-    else
-        hipLaunchKernelGGL((k_fill<E, NT, uint64_t>), dim3((unsigned int)n_tiles), dim3(KMX_BLOCK), 0, s, ix, arena, hit_off, tile_q, total, d, out);
+    FillVariant e = v;
+    if (!rec32) e.e = 8;
+    if (e.e != 4 && e.e != 8 && e.e != 12 && e.e != 16) e.e = 12;
+    return e;
 }
 
-void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
+void launch_fill(hipStream_t s, const FillVariant& v0, bool rec32, const KmxIndexDev* ix, const uint32_t* arena, const uint64_t* hit_off,
                  const uint32_t* tile_q, const unsigned long long* total, uint64_t n_tiles, const QueryDesc& d, uint32_t* out)
 {
-#define KMX_FILL_CASE(E_, NT_)                                                                         \
-    if (v.e == E_ && v.nt == NT_) {                                                                    \
-        launch_fill_rec<E_, NT_>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);         \
-        return;                                                                                        \
+    const FillVariant v = effective_fill_variant(v0, rec32);
+    const dim3 grid((unsigned int)n_tiles), block(KMX_BLOCK);
+    if (!rec32) {
+        if (v.nt) hipLaunchKernelGGL((k_fill<8, true, uint64_t>), grid, block, 0, s, ix, arena, hit_off, tile_q, total, d, out);
+        else hipLaunchKernelGGL((k_fill<8, false, uint64_t>), grid, block, 0, s, ix, arena, hit_off, tile_q, total, d, out);
+        return;
+    }
+#define KMX_FILL_CASE(E_, NT_)                                                                                          \
+    if (v.e == E_ && v.nt == NT_) {                                                                                     \
+        hipLaunchKernelGGL((k_fill<E_, NT_, uint32_t>), grid, block, 0, s, ix, arena, hit_off, tile_q, total, d, out);   \
+        return;                                                                                                         \
     }
     KMX_FILL_CASE(4, false)
     KMX_FILL_CASE(4, true)
@@ -1264,10 +1271,7 @@ void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndex
     KMX_FILL_CASE(12, true)
     KMX_FILL_CASE(16, false)
     KMX_FILL_CASE(16, true)
-    KMX_FILL_CASE(24, true)
-    KMX_FILL_CASE(32, true)
 #undef KMX_FILL_CASE
-    launch_fill_rec<8, true>(s, rec32, ix, arena, hit_off, tile_q, total, n_tiles, d, out);
 }
 
 void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,
@@ -1500,8 +1504,8 @@ void launch_build_phase1(hipStream_t s, const uint8_t* d_text, uint64_t n, uint3
 {
     const uint64_t npos = n - k + 1;
     const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks_for(npos, KMX_BLOCK), 256 * 64);
-    hipMemsetAsync(d_hist, 0, n_keys * sizeof(uint32_t), s);
-    hipMemsetAsync(d_info, 0, 4 * sizeof(unsigned int), s);
+    (void)hipMemsetAsync(d_hist, 0, n_keys * sizeof(uint32_t), s);
+    (void)hipMemsetAsync(d_info, 0, 4 * sizeof(unsigned int), s);
     hipLaunchKernelGGL(k_build_hist, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_hist);
     launch_scan(s, d_hist, n_keys, d_bsum, d_scratch_u64, d_total);
     hipLaunchKernelGGL(k_build_offsets, dim3(blocks_for(n_keys + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_scratch_u64, n_keys, d_offs,
@@ -1521,7 +1525,7 @@ void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint3
 {
     const uint64_t npos = n - k + 1;
     const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks_for(npos, KMX_BLOCK), 256 * 64);
-    hipMemcpyAsync(d_cursor, d_offs, n_keys * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpyAsync(d_cursor, d_offs, n_keys * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
     hipLaunchKernelGGL(k_build_scatter, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_cursor, d_region);
     const unsigned int wblocks = (unsigned int)std::min<uint64_t>((n_keys + 3) / 4, 256 * 32);
     hipLaunchKernelGGL(k_bucket_sort_wave, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_region);
