@@ -1,0 +1,128 @@
+"""Randomised differential test: engine (through the C-ABI) vs the CPU oracle over random index shapes,
+layouts and query mixes.  Seeds are fixed; a failure message carries the case so it can be replayed."""
+import numpy as np
+import pytest
+
+from kmer_index_amd import synth
+from tests.helpers import pack
+
+pytestmark = pytest.mark.gpu
+
+SIGMAS = [2, 3, 4, 5, 15, 20, 27]
+
+
+def _k_limit(sigma):
+    k = 1
+    while (sigma ** (k + 1)) < 2 ** 64 and (k + 1) < 64 / np.log2(sigma):
+        k += 1
+    return k
+
+
+def _fanout_ok(sigma, k, m):
+    """Keep the oracle fast: sub-k fan-outs either small or beyond the 1e7 guard (error path)."""
+    if m < k:
+        f = sigma ** (k - m)
+    elif m > k and m % k:
+        f = sigma ** (k - m % k)
+    else:
+        return True
+    return f <= 50_000 or f > 10_000_000
+
+
+def _make_case(rng):
+    sigma = int(rng.choice(SIGMAS))
+    klim = _k_limit(sigma)
+    n_ks = int(rng.integers(1, 4))
+    kmax_allowed = max(1, min(klim, int(np.log(2 ** 22) / np.log(sigma)) + int(rng.integers(0, 3))))
+    ks = sorted(set(int(x) for x in rng.integers(1, kmax_allowed + 1, n_ks)))
+    if rng.random() < 0.15:                                   # now and then a large k (sort-based flatten, open table)
+        ks = [int(rng.integers(min(klim, 14), klim + 1))]
+    rng.shuffle(ks)
+    kmax = max(ks)
+    n = int(rng.integers(kmax + 1, 200_000)) if rng.random() < 0.8 else int(rng.integers(kmax, kmax + 40))
+    style = rng.choice(["uniform", "lowent", "periodic"])
+    if style == "uniform":
+        text = synth.ranks(int(rng.integers(1, 1 << 30)), n, sigma)
+    elif style == "lowent":
+        text = (synth.ranks(int(rng.integers(1, 1 << 30)), n, sigma) * (synth.ranks(int(rng.integers(1, 1 << 30)), n, 4) == 0)).astype(np.uint8)
+    else:
+        period = int(rng.integers(1, 50))
+        text = np.resize(synth.ranks(int(rng.integers(1, 1 << 30)), period, sigma), n).astype(np.uint8)
+    return sigma, ks, text, style
+
+
+def _make_queries(rng, sigma, ks, text, count=260):
+    n = text.size
+    kmax = max(ks)
+    qs = []
+    lens_pool = [m for m in range(1, min(3 * kmax + 6, 70, n) + 1)]
+    for _ in range(count):
+        m = int(rng.choice(lens_pool))
+        # the planner may serve m from any k: require an oracle-friendly fan-out for every k of the index
+        if not all(_fanout_ok(sigma, k, m) for k in ks):
+            continue
+        r = rng.random()
+        if r < 0.3:
+            q = rng.integers(0, sigma, m).astype(np.uint8)
+        elif r < 0.8:
+            s0 = int(rng.integers(0, n - m + 1))
+            q = text[s0:s0 + m].copy()
+        else:
+            back = int(rng.integers(0, min(20, n - m) + 1))
+            q = text[n - m - back:n - back].copy()
+        qs.append(q)
+    qs.append(np.zeros(0, np.uint8))                         # empty query
+    if not qs:
+        qs.append(text[:1].copy())
+    return qs
+
+
+@pytest.mark.parametrize("seed", range(96))
+def test_random_index_and_queries(engine, orc, seed):
+    rng = np.random.default_rng(1000 + seed)
+    sigma, ks, text, style = _make_case(rng)
+    qs = _make_queries(rng, sigma, ks, text)
+    qranks, qoff = pack(qs)
+    oidx = orc.Index(text, sigma, ks)
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=8)
+    nkeys_max = max(sigma ** k for k in ks)
+    tables = [engine.TABLE_AUTO, engine.TABLE_OPEN] + ([engine.TABLE_DENSE] if nkeys_max <= (1 << 24) else [])
+    table = tables[int(rng.integers(0, len(tables)))]
+    kw = dict(table=table, aligned_copy=bool(rng.integers(0, 2)), host_flatten=bool(rng.integers(0, 2)))
+    case = f"seed={seed} sigma={sigma} ks={ks} n={text.size} text={style} {kw} queries={len(qs)}"
+    idx = engine.Index(text, sigma, ks, **kw)
+    flags = engine.SEARCH_KEEP_MASKS if seed % 3 == 0 else engine.SEARCH_DEFAULT
+    res = idx.search(qranks, qoff, flags=flags)
+    ho, pos, st, kd = res.host()
+    assert np.array_equal(st, o_st.astype(np.uint8)), case
+    assert np.array_equal(ho, o_off), case
+    assert np.array_equal(pos, o_pos), case
+    # second pass on the same handle (buffer reuse, speculative fill) must agree with itself
+    res2 = idx.search(qranks, qoff, result=res)
+    ho2, pos2, st2, kd2 = res2.host()
+    assert np.array_equal(ho2, ho) and np.array_equal(pos2, pos) and np.array_equal(kd2, kd), case
+    idx.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_large_batches(engine, orc, seed):
+    """The same, with batches of ~20 K queries (many blocks, many tiles, long work lists, ragged tails)."""
+    rng = np.random.default_rng(5000 + seed)
+    sigma, ks, text, style = _make_case(rng)
+    if text.size < 2000:
+        text = np.resize(text, 2000 + seed).astype(np.uint8)
+    qs = _make_queries(rng, sigma, ks, text, count=int(rng.integers(15_000, 25_000)))
+    qranks, qoff = pack(qs)
+    oidx = orc.Index(text, sigma, ks)
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=8)
+    kw = dict(table=[engine.TABLE_AUTO, engine.TABLE_OPEN][seed % 2], aligned_copy=bool(seed % 3), host_flatten=bool(seed % 5 == 0))
+    case = f"seed={seed} sigma={sigma} ks={ks} n={text.size} text={style} {kw} queries={len(qs)} hits={int(o_off[-1])}"
+    idx = engine.Index(text, sigma, ks, **kw)
+    res = engine.Result()
+    for _ in range(2):                                   # the second pass takes the steady-state (speculative) path
+        idx.search(qranks, qoff, result=res)
+        ho, pos, st, kd = res.host()
+        assert np.array_equal(st, o_st.astype(np.uint8)), case
+        assert np.array_equal(ho, o_off), case
+        assert np.array_equal(pos, o_pos), case
+    idx.close()
