@@ -783,36 +783,87 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
                                                          uint64_t* __restrict__ out, uint64_t tile,
                                                          uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q)
 {
-    // blocked arrangement: thread t owns items [t*ITEMS, (t+1)*ITEMS) of the tile
-    const uint64_t base = uint64_t(blockIdx.x) * KMX_SCAN_TILE + uint64_t(threadIdx.x) * KMX_SCAN_ITEMS;
-    uint32_t v[KMX_SCAN_ITEMS];
-    uint64_t s = 0;
+    // The block's 4096 items as KMX_SCAN_ROWS rows of 1024: in row r thread t owns items r*1024 + 4t .. 4t+3 —
+    // one coalesced 16-byte load and two 16-byte stores per row.  The rows are scanned together (one set of
+    // wave shuffles and barriers for all of them).
+    constexpr int ROWS = KMX_SCAN_ITEMS / 4;
+    __shared__ uint64_t wave_sum[ROWS][KMX_BLOCK / KMX_WAVE];
+    const uint32_t lane = lane_id(), w = threadIdx.x / KMX_WAVE;
+    const uint64_t block_base = uint64_t(blockIdx.x) * KMX_SCAN_TILE;
+    uint32_t v[ROWS][4];
+    uint64_t inc[ROWS];
 #pragma unroll
-    for (int j = 0; j < KMX_SCAN_ITEMS; ++j) {
-        uint64_t i = base + j;
-        v[j] = i < n ? in[i] : 0;
-        s += v[j];
+    for (int r = 0; r < ROWS; ++r) {
+        const uint64_t i = block_base + uint64_t(r) * (KMX_BLOCK * 4) + uint64_t(threadIdx.x) * 4;
+        if (i + 3 < n) {
+            const uint4 t = *reinterpret_cast<const uint4*>(in + i);
+            v[r][0] = t.x; v[r][1] = t.y; v[r][2] = t.z; v[r][3] = t.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[r][j] = i + j < n ? in[i + j] : 0u;
+        }
+        inc[r] = uint64_t(v[r][0]) + v[r][1] + v[r][2] + v[r][3];
     }
-    uint64_t ex = block_exclusive_scan_u64(s, nullptr) + bsum[blockIdx.x];
+    uint64_t own[ROWS];
 #pragma unroll
-    for (int j = 0; j < KMX_SCAN_ITEMS; ++j) {
-        uint64_t i = base + j;
-        if (i < n) out[i] = ex;
-        if constexpr (TILES) {
-            if (i < n && v[j]) {
-                // boundaries x = t*tile with ex <= x < ex + v[j]
-                uint64_t t = (ex + tile - 1) / tile;
-                const uint64_t t_end = (ex + v[j] - 1) / tile;
-                for (; t <= t_end && t <= n_tiles_cap; ++t) tile_q[t] = uint32_t(i);
+    for (int r = 0; r < ROWS; ++r) own[r] = inc[r];
+    for (int off = 1; off < KMX_WAVE; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) {
+            const uint64_t t = __shfl_up(inc[r], off);
+            if (lane >= uint32_t(off)) inc[r] += t;
+        }
+    }
+    if (lane == KMX_WAVE - 1) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) wave_sum[r][w] = inc[r];
+    }
+    __syncthreads();
+    uint64_t row_base = bsum[blockIdx.x];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        uint64_t carry = 0, total = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i) {
+            const uint64_t sw = wave_sum[r][i];
+            if (i < w) carry += sw;
+            total += sw;
+        }
+        uint64_t ex = row_base + carry + inc[r] - own[r];
+        row_base += total;
+        const uint64_t i0 = block_base + uint64_t(r) * (KMX_BLOCK * 4) + uint64_t(threadIdx.x) * 4;
+        uint64_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint64_t i = i0 + j;
+            o[j] = ex;
+            if constexpr (TILES) {
+                if (i < n && v[r][j]) {
+                    // boundaries x = t*tile with ex <= x < ex + v
+                    uint64_t t = (ex + tile - 1) / tile;
+                    const uint64_t t_end = (ex + v[r][j] - 1) / tile;
+                    for (; t <= t_end && t <= n_tiles_cap; ++t) tile_q[t] = uint32_t(i);
+                }
+            }
+            ex += v[r][j];
+            if (i + 1 == n) {
+                out[n] = ex;
+                if constexpr (TILES) {
+                    // boundaries at or beyond the total: the last query
+                    for (uint64_t t = (ex + tile - 1) / tile; t <= n_tiles_cap && t <= (ex + tile - 1) / tile + 1; ++t) tile_q[t] = uint32_t(n - 1);
+                }
             }
         }
-        ex += v[j];
-        if (i + 1 == n) {
-            out[n] = ex;
-            if constexpr (TILES) {
-                // boundaries at or beyond the total: the last query
-                for (uint64_t t = (ex + tile - 1) / tile; t <= n_tiles_cap && t <= (ex + tile - 1) / tile + 1; ++t) tile_q[t] = uint32_t(n - 1);
-            }
+        if (i0 + 3 < n) {
+            typedef uint64_t u64x2s __attribute__((ext_vector_type(2)));
+            u64x2s a, c;
+            a[0] = o[0]; a[1] = o[1]; c[0] = o[2]; c[1] = o[3];
+            *reinterpret_cast<u64x2s*>(out + i0) = a;
+            *reinterpret_cast<u64x2s*>(out + i0 + 2) = c;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (i0 + j < n) out[i0 + j] = o[j];
         }
     }
     if (n == 0 && blockIdx.x == 0 && threadIdx.x == 0) out[0] = 0;
