@@ -1094,24 +1094,35 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_compact(const uint32_t* __restric
                                                        const uint64_t* __restrict__ hit_off,
                                                        uint32_t* __restrict__ out)
 {
+    // KMX_VGROUPS queries per wave, one per KMX_VGROUP-lane group (the chain list -> descriptor -> word ->
+    // candidate -> store is latency bound, so several queries are kept in flight per wave)
     const uint32_t lane = lane_id();
+    const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
-    for (uint64_t i = wave; i < n_stitch; i += n_waves) {
-        const uint32_t q = d.stitch_list[i];
-        if (d.cnt[q] == 0) continue;
-        const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q] & ~SRC_FLAGS;
-        const uint64_t* __restrict__ words = mask_words + d.aux[q];
-        uint64_t o = hit_off[q];
-        const uint32_t n_words = c0 / 64 + 1;
-        for (uint32_t w = 0; w < n_words; ++w) {
-            const uint64_t word = words[w];
-            if ((word >> lane) & 1) {
-                const uint32_t rank = uint32_t(__popcll(word & ((uint64_t(1) << lane) - 1)));
-                out[o + rank] = arena[src + uint64_t(w) * 64 + lane];
+    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
+        const uint64_t i = i0 + g;
+        const bool have = i < n_stitch;
+        const uint32_t q = have ? d.stitch_list[i] : 0u;
+        const uint32_t valid = have ? d.cnt[q] : 0u;
+        const uint32_t c0 = (have && valid) ? d.c0[q] : 0u;               // nothing to copy when no candidate survived
+        const uint64_t src = have ? (d.src[q] & ~SRC_FLAGS) : 0;
+        const uint64_t* __restrict__ words = mask_words + (have ? d.aux[q] : 0);
+        uint64_t o = have ? hit_off[q] : 0;
+        const uint32_t n_it = (c0 + KMX_VGROUP - 1) / KMX_VGROUP;
+        uint32_t max_it = n_it;
+        for (int off = 32; off > 0; off >>= 1) max_it = max(max_it, uint32_t(__shfl_xor(int(max_it), off)));
+        uint64_t word = 0;
+        for (uint32_t it = 0; it < max_it; ++it) {
+            if (it < n_it && (it % KMX_VSLICES) == 0) word = words[it / KMX_VSLICES];
+            const uint32_t slice = uint32_t((word >> (KMX_VGROUP * (it % KMX_VSLICES))) & ((uint64_t(1) << KMX_VGROUP) - 1));
+            if (it < n_it) {
+                if ((slice >> gl) & 1u) {
+                    const uint32_t rank = uint32_t(__popc(slice & ((1u << gl) - 1u)));
+                    out[o + rank] = arena[src + uint64_t(it) * KMX_VGROUP + gl];
+                }
+                o += uint64_t(__popc(slice));
             }
-            o += uint64_t(__popcll(word));
         }
     }
 }
@@ -1328,7 +1339,8 @@ void launch_fill(hipStream_t s, const FillVariant& v0, bool rec32, const KmxInde
 void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,
                     const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out)
 {
-    unsigned int blocks = (unsigned int)std::min<uint64_t>((n_stitch + 3) / 4, 256 * 32);
+    const uint64_t cwaves = (n_stitch + KMX_VGROUPS - 1) / KMX_VGROUPS;
+    unsigned int blocks = (unsigned int)std::min<uint64_t>((cwaves + 3) / 4, 256 * 32);
     hipLaunchKernelGGL(k_compact, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, arena, d, n_stitch, mask_words, hit_off, out);
 }
 
