@@ -175,6 +175,17 @@ namespace kmer
         const kmx_index* handle() const { return _index.get(); }
     };
 
+    // choose_best_k.hpp:12-60 — which ks to instantiate for a set of query lengths
+    template<std::ranges::range range_t>
+    std::vector<std::size_t> choose_best_k(range_t&& interval, std::size_t n_k = 4)
+    {
+        std::vector<std::uint64_t> lengths;
+        for (auto v : interval) lengths.push_back(std::uint64_t(v));
+        std::vector<std::uint32_t> ks(n_k);
+        detail::throw_on(kmx_choose_best_k(lengths.data(), lengths.size(), std::uint32_t(n_k), ks.data()), "choose_best_k");
+        return std::vector<std::size_t>(ks.begin(), ks.end());
+    }
+
     // kmer_index.hpp:569-579
     template<std::size_t... ks, std::ranges::range text_t>
     auto make_kmer_index(text_t&& text, std::size_t n_threads = std::thread::hardware_concurrency())

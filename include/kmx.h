@@ -129,6 +129,11 @@ kmx_status kmx_index_extend_query_size_range(kmx_index* index, uint32_t new_maxi
 kmx_status kmx_plan(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint8_t* use_multi,
                     uint32_t* nk_off, uint32_t* nk_flat, uint64_t cap, uint64_t* n_flat);
 
+/* choose_best_k (choose_best_k.hpp:12-60): the n_k (<= 10) values of k the reference's heuristic recommends for a
+ * set of query lengths — candidates {29,27,25,23,21,19,17,13,11,10}, 3 points for a length the candidate divides,
+ * 4 - miss points for a miss of at most 3, best scores first.  Pure host code. */
+kmx_status kmx_choose_best_k(const uint64_t* query_lengths, uint64_t n_lengths, uint32_t n_k, uint32_t* ks_out);
+
 /* kmer::detail::fast_pow (fast_pow.hpp:46-93), including its "0 on exp >= 63" rule. */
 uint64_t kmx_fast_pow(uint64_t base, uint8_t exp);
 

@@ -368,6 +368,15 @@ uint32_t kmx_version(void) { return KMX_VERSION; }
 
 uint64_t kmx_fast_pow(uint64_t base, uint8_t exp) { return kmx::fast_pow(base, exp); }
 
+kmx_status kmx_choose_best_k(const uint64_t* query_lengths, uint64_t n_lengths, uint32_t n_k, uint32_t* ks_out)
+{
+    if ((!query_lengths && n_lengths) || !ks_out || n_k == 0 || n_k > 10)
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_choose_best_k: need lengths, an output array and 1..10 values of k");
+    const std::vector<uint32_t> ks = kmx::choose_best_k(query_lengths, n_lengths, n_k);
+    for (size_t i = 0; i < ks.size(); ++i) ks_out[i] = ks[i];
+    return KMX_OK;
+}
+
 kmx_status kmx_plan(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint8_t* use_multi, uint32_t* nk_off,
                     uint32_t* nk_flat, uint64_t cap, uint64_t* n_flat)
 {

@@ -100,6 +100,29 @@ std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uin
     return out;
 }
 
+// choose_best_k.hpp:12-60.  Candidates in descending priority (:22-23); every query length gives points to the
+// FIRST candidate that divides it (3 points, :32-36) or misses a multiple by at most 3 (4 - miss points, :38-42);
+// the candidates are then ordered by score (:50-51) and the first n_k returned (:55-57).  The reference sorts
+// with std::sort (order of equal scores unspecified); equal scores keep the priority order here.
+std::vector<uint32_t> choose_best_k(const uint64_t* lengths, uint64_t n_lengths, uint32_t n_k)
+{
+    static const uint32_t candidates[] = {29, 27, 25, 23, 21, 19, 17, 13, 11, 10};
+    std::vector<std::pair<uint32_t, uint64_t>> k_and_score;
+    for (uint32_t k : candidates) k_and_score.emplace_back(k, 0);
+    for (uint64_t j = 0; j < n_lengths; ++j) {
+        const uint64_t i = lengths[j];
+        for (auto& p : k_and_score) {
+            const uint64_t k = p.first;
+            if (i % k == 0) { p.second += 3; break; }
+            if (k - (i % k) <= 3) { p.second += 4 - (k - (i % k)); break; }
+        }
+    }
+    std::stable_sort(k_and_score.begin(), k_and_score.end(), [](const auto& a, const auto& b) { return a.second > b.second; });
+    std::vector<uint32_t> out;
+    for (uint32_t i = 0; i < n_k && i < k_and_score.size(); ++i) out.push_back(k_and_score[i].first);
+    return out;
+}
+
 static uint32_t ceil_log2_u64(uint64_t v)
 {
     uint32_t l = 0;

@@ -19,6 +19,9 @@ Plan make_plan(const std::vector<uint32_t>& ks, uint32_t range);
 // Device form of the plan for an index holding `ks` (template order).
 std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uint32_t range);
 
+// choose_best_k (choose_best_k.hpp:12-60): which n_k values of k to instantiate for a set of query lengths.
+std::vector<uint32_t> choose_best_k(const uint64_t* lengths, uint64_t n_lengths, uint32_t n_k);
+
 // Host image of one flattened kmer_index_element.
 struct ElemImage {
     uint32_t k = 0;

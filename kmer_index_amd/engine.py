@@ -19,7 +19,7 @@ Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
 
 # every symbol include/kmx.h declares
 EXPORTS = [
-    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_plan", "kmx_fast_pow",
+    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_choose_best_k", "kmx_plan", "kmx_fast_pow",
     "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
@@ -74,6 +74,8 @@ def lib():
         L.kmx_index_arena_host.argtypes = [vp, P(vp), P(u64)]
         L.kmx_index_extend_query_size_range.restype = C.c_int
         L.kmx_index_extend_query_size_range.argtypes = [vp, u32]
+        L.kmx_choose_best_k.restype = C.c_int
+        L.kmx_choose_best_k.argtypes = [vp, u64, u32, vp]
         L.kmx_plan.restype = C.c_int
         L.kmx_plan.argtypes = [vp, u32, u32, vp, vp, vp, u64, P(u64)]
         L.kmx_fast_pow.restype = u64
@@ -114,6 +116,14 @@ def _check(st):
 
 def fast_pow(base, exp):
     return int(lib().kmx_fast_pow(base, exp))
+
+
+def choose_best_k(lengths, n_k=4):
+    """kmx_choose_best_k (choose_best_k.hpp): recommended ks for a set of query lengths."""
+    lengths = np.ascontiguousarray(lengths, np.uint64)
+    out = np.zeros(n_k, np.uint32)
+    _check(lib().kmx_choose_best_k(lengths.ctypes.data, lengths.size, n_k, out.ctypes.data))
+    return out.tolist()
 
 
 def plan(ks, rng=10000):

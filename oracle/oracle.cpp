@@ -468,6 +468,24 @@ typedef struct orc_index orc_index;
 
 uint64_t orc_fast_pow(uint64_t base, uint8_t exp) { return orc::fast_pow(base, exp); }
 
+// choose_best_k — choose_best_k.hpp:12-60, restated loop for loop (equal scores keep the candidate order).
+void orc_choose_best_k(const uint64_t* interval, uint64_t n, uint32_t n_k, uint32_t* out)
+{
+    std::vector<std::pair<uint64_t, uint64_t>> k_and_score;
+    for (uint64_t k : {29, 27, 25, 23, 21, 19, 17, 13, 11, 10}) k_and_score.emplace_back(k, 0);          // :22-23
+    for (uint64_t j = 0; j < n; ++j) {                                                                     // :25
+        const uint64_t i = interval[j];
+        for (auto& p : k_and_score) {                                                                      // :27
+            const uint64_t k = p.first;
+            if (i % k == 0) { p.second += 3; break; }                                                      // :32-36
+            else if (k - (i % k) <= 3) { p.second += 4 - (k - (i % k)); break; }                           // :38-42
+            else continue;                                                                                 // :44-45
+        }
+    }
+    std::stable_sort(k_and_score.begin(), k_and_score.end(), [](auto a, auto b) { return a.second > b.second; });   // :50-51
+    for (uint32_t i = 0; i < n_k; ++i) out[i] = uint32_t(k_and_score.at(i).first);                         // :55-57
+}
+
 // Replays a list of bit operations on a compressed_bitset and returns its words.
 // ops[i] = (index << 1) | value.  Returns the word count, or -1 when an index is
 // out of range (the reference throws std::out_of_range there).

@@ -39,6 +39,7 @@ def lib():
         L = C.CDLL(path)
         L.orc_fast_pow.restype = C.c_uint64
         L.orc_fast_pow.argtypes = [C.c_uint64, C.c_uint8]
+        L.orc_choose_best_k.argtypes = [_u64p, C.c_uint64, C.c_uint32, _u32p]
         L.orc_bitset_words.restype = C.c_int64
         L.orc_bitset_words.argtypes = [C.c_uint64, C.c_int, _u64p, C.c_uint64, _u64p, C.c_uint64, C.POINTER(C.c_uint64)]
         L.orc_plan.restype = C.c_uint64
@@ -90,6 +91,13 @@ def _take(ptr, n, dtype):
 
 def fast_pow(base: int, exp: int) -> int:
     return int(lib().orc_fast_pow(base, exp))
+
+
+def choose_best_k(lengths, n_k=4):
+    lengths = np.ascontiguousarray(lengths, np.uint64)
+    out = np.zeros(n_k, np.uint32)
+    lib().orc_choose_best_k(lengths if lengths.size else np.zeros(1, np.uint64), lengths.size, n_k, out)
+    return out.tolist()
 
 
 def bitset_words(n_bits, fill, ops, which="orc"):

@@ -116,3 +116,15 @@ def test_index_load_rejects_bad_images_before_touching_the_device(engine, tmp_pa
     with pytest.raises(engine.KmxError) as e:
         engine.Index.load(str(trunc))
     assert e.value.status == 1 and "truncated" in str(e.value)
+
+
+def test_choose_best_k_matches_oracle_and_known_answer(engine, orc):
+    """choose_best_k.hpp:12-60.  Hand-computed: lengths {20, 40, 60} -> 20 gives k=23 one point (miss 3), 40 gives k=21
+    two points (miss 2), 60 gives k=21 one point (miss 3): scores 21:3, 23:1, rest 0 in priority order."""
+    assert engine.choose_best_k([20, 40, 60], 4) == [21, 23, 29, 27] == orc.choose_best_k([20, 40, 60], 4)
+    assert engine.choose_best_k([29 * 3, 58, 27, 10, 11], 3) == orc.choose_best_k([29 * 3, 58, 27, 10, 11], 3)
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        lens = rng.integers(1, 2000, int(rng.integers(0, 300)))
+        n_k = int(rng.integers(1, 11))
+        assert engine.choose_best_k(lens, n_k) == orc.choose_best_k(lens, n_k)
