@@ -793,7 +793,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         timed(ix, K_PREFIX_SORT_BLOCK, s, [&] { kmx::launch_prefix_sort_block(s, d_big, n_prefix_big, hit_off, out); });
 
     if (n_prefix_big && max_runs > 1 && prefix_elems > 0) {
-        // slices beyond the block sort's capacity: merge the per-key runs in global memory
+        // slices beyond the block sort's capacity: their 32 K chunks are sorted by now, merge the chunks
         const uint64_t np = n_prefix_big;
         HIP_TRY(r->plen.ensure(np * 4));
         HIP_TRY(r->poff.ensure((np + 1) * 8));
@@ -808,7 +808,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         int src_is_out = 1;
         for (uint32_t p = 0; p < passes; ++p) {
             timed(ix, K_MERGE_PASS, s, [&] {
-                kmx::launch_merge_pass(s, dix, qr, qo, d_big, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out,
+                kmx::launch_merge_pass(s, d_big, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out,
                                        r->ptmp.as<uint32_t>(), p, src_is_out);
             });
             src_is_out = !src_is_out;

@@ -56,8 +56,7 @@ void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
                               const uint64_t* hit_off, uint32_t* out);
 void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off, uint32_t* out);
-void launch_merge_pass(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
-                       const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
+void launch_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
                        const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass, int src_is_out);
 void launch_prefix_copy_back(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff,
                              uint64_t p_total, const uint64_t* hit_off, uint32_t* out, const uint32_t* tmp);

@@ -462,9 +462,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
         } else {
             loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
-            if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: global merge passes
+            if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: chunks sorted in LDS, then merged in global memory
                 atomicAdd(&bc.pelems, (unsigned long long)plen);
-                atomicMax(&bc.max_runs, c0);
+                atomicMax(&bc.max_runs, (plen + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP);
             }
         }
     }
@@ -1195,43 +1195,34 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
     }
 }
 
-__global__ __launch_bounds__(KMX_BLOCK) void k_merge_pass(const KmxIndexDev* __restrict__ ix,
-                                                          const uint8_t* __restrict__ qranks,
-                                                          const uint64_t* __restrict__ qoff, QueryDesc d,
-                                                          uint64_t n_prefix, const uint64_t* __restrict__ poff,
-                                                          uint64_t p_total, const uint64_t* __restrict__ hit_off,
+__global__ __launch_bounds__(KMX_BLOCK) void k_merge_pass(QueryDesc d, uint64_t n_prefix,
+                                                          const uint64_t* __restrict__ poff, uint64_t p_total,
+                                                          const uint64_t* __restrict__ hit_off,
                                                           uint32_t* __restrict__ out, uint32_t* __restrict__ tmp,
                                                           uint32_t pass, int src_is_out)
 {
+    // The slice of a large PREFIX query is a row of KMX_PSORT_BLOCK_CAP-position chunks, each already sorted by
+    // k_prefix_sort_block; pass t merges neighbouring groups of 2^t chunks by ranking every position in its
+    // sibling group (positions are distinct, so ranks are unique).
     const uint64_t e = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
     if (e >= p_total) return;
     const uint64_t i = upper_bound_dev<uint64_t>(poff, n_prefix + 1, e) - 1;
     const uint32_t q = d.prefix_list[i];
     const uint64_t idx = e - poff[i];
+    const uint64_t len = poff[i + 1] - poff[i];
     const uint32_t* __restrict__ in = src_is_out ? out + hit_off[q] : tmp + poff[i];
     uint32_t* __restrict__ ot = src_is_out ? tmp + poff[i] : out + hit_off[q];
-
-    const uint64_t m = qoff[q + 1] - qoff[q];
-    const KmxPlanEntry pe = load_plan(ix, m);
-    const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
-    const KMX_GLOBAL uint32_t* offs = as_global(el->offs) + d.key[q];   // run r spans [offs[r]-offs[0], offs[r+1]-offs[0])
-    const uint32_t n_runs = d.c0[q];
-    const uint32_t o0 = offs[0];
-
+    const uint64_t CH = KMX_PSORT_BLOCK_CAP;
+    const uint64_t n_runs = (len + CH - 1) / CH;
     const uint32_t x = in[idx];
-    // run that holds idx: last r with offs[r] - o0 <= idx
-    const uint64_t r = upper_bound_dev<uint32_t>(offs, uint64_t(n_runs) + 1, uint32_t(o0 + idx)) - 1;
-    const uint64_t g = r >> pass;
-    const uint64_t sib = g ^ 1;
-    const uint64_t sib_first = sib << pass;
+    const uint64_t g = (idx / CH) >> pass;
+    const uint64_t sib_first = (g ^ 1) << pass;
     if (sib_first >= n_runs) { ot[idx] = x; return; }          // no sibling group: carried over
-    const uint64_t own_first = g << pass;
-    const uint32_t own_lo = offs[own_first] - o0;
-    const uint32_t sib_lo = offs[sib_first] - o0;
-    const uint32_t sib_hi = offs[min(uint64_t(n_runs), sib_first + (uint64_t(1) << pass))] - o0;
+    const uint64_t own_lo = (g << pass) * CH;
+    const uint64_t sib_lo = sib_first * CH;
+    const uint64_t sib_hi = min(len, (sib_first + (uint64_t(1) << pass)) * CH);
     const uint64_t rank = lower_bound_dev<uint32_t>(in + sib_lo, sib_hi - sib_lo, x);
-    const uint32_t pair_lo = min(own_lo, sib_lo);
-    ot[pair_lo + (idx - own_lo) + rank] = x;
+    ot[min(own_lo, sib_lo) + (idx - own_lo) + rank] = x;
 }
 
 __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_copy_back(QueryDesc d, uint64_t n_prefix,
@@ -1350,6 +1341,24 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 }
 
 
+// bitonic sort of n2 (power of two) LDS words by `nthreads` cooperating threads; `sync` separates the stages
+template <typename Sync>
+__device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_t tid, uint32_t nthreads, Sync sync)
+{
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = sbuf[lo], b = sbuf[hi];
+                if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
+            }
+            sync();
+        }
+    }
+}
+
 // PREFIX slices that are too long or have too many runs for k_prefix_sort_small but fit 128 KB of
 // LDS: one 1024-thread block per query, bitonic sort of the slice padded to a power of two.
 #define KMX_PSB_THREADS 1024
@@ -1357,6 +1366,7 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc
                                                                         const uint64_t* __restrict__ hit_off,
                                                                         uint32_t* __restrict__ out)
 {
+    // mid-size slices whole; slices beyond the capacity chunk by chunk (k_merge_pass merges the chunks afterwards)
     extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];
     const uint32_t tid = threadIdx.x;
     for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
@@ -1364,26 +1374,20 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc
         const uint32_t R = d.c0[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
         const bool small = R <= KMX_PSORT_MAX_RUNS && len <= KMX_PSORT_CAP;
-        if (small || len > KMX_PSORT_BLOCK_CAP || R < 2 || len < 2) continue;           // block-uniform
-        uint32_t n2 = 1;
-        while (n2 < len) n2 <<= 1;
-        uint32_t* __restrict__ seg = out + hit_off[q];
-        for (uint32_t t = tid; t < n2; t += KMX_PSB_THREADS) sbuf[t] = t < len ? seg[t] : 0xFFFFFFFFu;
-        __syncthreads();
-        for (uint32_t size = 2; size <= n2; size <<= 1) {
-            for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-                for (uint32_t t = tid; t < n2 / 2; t += KMX_PSB_THREADS) {
-                    const uint32_t lo = 2 * t - (t & (stride - 1));                      // pair (lo, lo + stride)
-                    const uint32_t hi = lo + stride;
-                    const bool up = (lo & size) == 0;
-                    const uint32_t a = sbuf[lo], b = sbuf[hi];
-                    if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
-                }
-                __syncthreads();
-            }
+        if (small || R < 2 || len < 2) continue;                                          // block-uniform
+        const uint32_t n_chunks = (len + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP;
+        for (uint32_t c = blockIdx.y; c < n_chunks; c += gridDim.y) {
+            const uint32_t c_lo = c * KMX_PSORT_BLOCK_CAP;
+            const uint32_t c_len = min(uint32_t(KMX_PSORT_BLOCK_CAP), len - c_lo);
+            uint32_t n2 = 2;
+            while (n2 < c_len) n2 <<= 1;
+            uint32_t* __restrict__ seg = out + hit_off[q] + c_lo;
+            for (uint32_t t = tid; t < n2; t += KMX_PSB_THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
+            __syncthreads();
+            bitonic_lds(sbuf, n2, tid, uint32_t(KMX_PSB_THREADS), [] { __syncthreads(); });
+            for (uint32_t t = tid; t < c_len; t += KMX_PSB_THREADS) seg[t] = sbuf[t];
+            __syncthreads();
         }
-        for (uint32_t t = tid; t < len; t += KMX_PSB_THREADS) seg[t] = sbuf[t];
-        __syncthreads();
     }
 }
 
@@ -1396,7 +1400,8 @@ void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_pref
         attr_set = true;
     }
     unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
-    hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1), dim3(KMX_PSB_THREADS), lds, s, d, n_prefix, hit_off, out);
+    const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks
+    hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(KMX_PSB_THREADS), lds, s, d, n_prefix, hit_off, out);
 }
 
 // ---------------------------------------------------------------------------
@@ -1445,24 +1450,6 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_build_scatter(const uint8_t* __re
     const uint64_t stride = uint64_t(gridDim.x) * KMX_BLOCK;
     for (uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x; i < npos; i += stride)
         positions[atomicAdd(&cursor[kmer_hash_at(text, i, k, sigma)], 1u)] = uint32_t(i);
-}
-
-// bitonic sort of n2 (power of two) LDS words by `nthreads` cooperating threads; `sync` separates the stages
-template <typename Sync>
-__device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_t tid, uint32_t nthreads, Sync sync)
-{
-    for (uint32_t size = 2; size <= n2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint32_t a = sbuf[lo], b = sbuf[hi];
-                if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
-            }
-            sync();
-        }
-    }
 }
 
 // one wave per bucket of at most KMX_PSORT_CAP positions
@@ -1623,12 +1610,11 @@ void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64
     hipLaunchKernelGGL(k_prefix_sort_small, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, out);
 }
 
-void launch_merge_pass(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
-                       const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
+void launch_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
                        const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass, int src_is_out)
 {
-    hipLaunchKernelGGL(k_merge_pass, dim3(blocks_for(p_total, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, d,
-                       n_prefix, poff, p_total, hit_off, out, tmp, pass, src_is_out);
+    hipLaunchKernelGGL(k_merge_pass, dim3(blocks_for(p_total, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, poff, p_total,
+                       hit_off, out, tmp, pass, src_is_out);
 }
 
 void launch_prefix_copy_back(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff,

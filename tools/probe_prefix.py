@@ -15,7 +15,7 @@ text = synth.ranks(1002, n, sigma)
 idx = engine.Index(text, sigma, [k])
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-for m, nq in ((9, 2_000_000), (8, 1_000_000), (6, 50_000), (13, 2_000_000), (25, 2_000_000)):
+for m, nq in ((9, 2_000_000), (8, 1_000_000), (6, 50_000), (5, 10_000), (3, 300), (13, 2_000_000), (25, 2_000_000)):
     q, off = synth.uniform_queries(77 + m, nq, m, sigma)
     if m > k:   # plant half so that stitches survive
         q, off = synth.mixed_queries(77 + m, text, nq, [m], sigma)
