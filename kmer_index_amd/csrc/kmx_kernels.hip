@@ -25,6 +25,9 @@
 #define KMX_BLOCK 256
 #define KMX_WAVE 64
 #define KMX_LOOKUP_ITEMS 4     // queries per thread in k_lookup
+#ifndef KMX_PSORT_MULTIWAY_RUNS
+#define KMX_PSORT_MULTIWAY_RUNS 4   // k_prefix_sort_small: multi-way rank pass up to this many runs, bitonic beyond
+#endif
 #define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
 
 namespace kmx {
@@ -168,6 +171,24 @@ __device__ __forceinline__ bool rank_hash(const uint8_t* __restrict__ q, uint32_
     }
     h = acc;
     return ok;
+}
+
+// bitonic sort of n2 (power of two) LDS words by `nthreads` cooperating threads; `sync` separates the stages
+template <typename Sync>
+__device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_t tid, uint32_t nthreads, Sync sync)
+{
+    for (uint32_t size = 2; size <= n2; size <<= 1) {
+        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
+            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
+                const uint32_t lo = 2 * t - (t & (stride - 1));
+                const uint32_t hi = lo + stride;
+                const bool up = (lo & size) == 0;
+                const uint32_t a = sbuf[lo], b = sbuf[hi];
+                if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
+            }
+            sync();
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1172,10 +1193,25 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
         const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
         if (lane <= R) bnd[wv][lane] = offs[lane] - offs[0];
         uint32_t* __restrict__ seg = out + hit_off[q];
+        auto wsync = [] {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        };
+        if (R > KMX_PSORT_MULTIWAY_RUNS) {
+            // many runs: a bitonic sort of the staged slice (independent compare-exchanges per stage) beats
+            // R - 1 dependent binary searches per position
+            uint32_t n2 = 2;
+            while (n2 < len) n2 <<= 1;
+            for (uint32_t t = lane; t < n2; t += KMX_WAVE) buf[wv][t] = t < len ? seg[t] : 0xFFFFFFFFu;
+            wsync();
+            bitonic_lds(buf[wv], n2, lane, uint32_t(KMX_WAVE), wsync);
+            for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][t];
+            wsync();
+            continue;
+        }
         for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][t] = seg[t];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wsync();
         for (uint32_t t = lane; t < len; t += KMX_WAVE) {
             const uint32_t x = buf[wv][t];
             uint32_t pos = 0;
@@ -1340,24 +1376,6 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
     hipLaunchKernelGGL(k_prefix_len, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, plen);
 }
 
-
-// bitonic sort of n2 (power of two) LDS words by `nthreads` cooperating threads; `sync` separates the stages
-template <typename Sync>
-__device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_t tid, uint32_t nthreads, Sync sync)
-{
-    for (uint32_t size = 2; size <= n2; size <<= 1) {
-        for (uint32_t stride = size >> 1; stride > 0; stride >>= 1) {
-            for (uint32_t t = tid; t < n2 / 2; t += nthreads) {
-                const uint32_t lo = 2 * t - (t & (stride - 1));
-                const uint32_t hi = lo + stride;
-                const bool up = (lo & size) == 0;
-                const uint32_t a = sbuf[lo], b = sbuf[hi];
-                if ((a > b) == up) { sbuf[lo] = b; sbuf[hi] = a; }
-            }
-            sync();
-        }
-    }
-}
 
 // PREFIX slices that are too long or have too many runs for k_prefix_sort_small but fit 128 KB of
 // LDS: one 1024-thread block per query, bitonic sort of the slice padded to a power of two.
