@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Turns gpurun_out/prof_<tag>/ (written by tools/profile_round.sh on the GPU box) into the tracked evidence:
+
+  profiles/r01_bench_<tag>.json          the bench line of that run
+  profiles/r01_kernel_stats_<tag>.csv    rocprofv3 --kernel-trace --stats summary (kmx kernels + copies)
+  profiles/r01_pmc_summary_<tag>.json    per-kernel FETCH_SIZE / WRITE_SIZE (separate passes), corrected as
+                                         MI355X_MICROARCH.md prescribes for gfx950 (FETCH_SIZE x2), per launch
+  profiles/pmc_summary_current.json      what bench.py reads `roofline.traffic` from
+
+Usage: python tools/summarise_profiles.py <tag> [--round r01]
+"""
+import argparse
+import csv
+import json
+import os
+import re
+import shutil
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    return re.sub(r"\(.*$", "", name)
+
+
+def counters(path, counter):
+    per = defaultdict(list)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == counter and "kmx::" in row["Kernel_Name"]:
+                per[short(row["Kernel_Name"])].append(float(row["Counter_Value"]))
+    return per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--round", default="r01")
+    a = ap.parse_args()
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
+    dst = os.path.join(ROOT, "profiles")
+    bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
+    with open(os.path.join(dst, f"{a.round}_bench_{a.tag}.json"), "w") as f:
+        json.dump(bench, f, indent=1)
+    shutil.copy(os.path.join(src, "kt", "kt_kernel_stats.csv"), os.path.join(dst, f"{a.round}_kernel_stats_{a.tag}.csv"))
+
+    avg_ns = {}
+    with open(os.path.join(src, "kt", "kt_kernel_stats.csv"), newline="") as f:
+        for row in csv.DictReader(f):
+            avg_ns[short(row["Name"])] = (float(row["AverageNs"]), int(row["Calls"]))
+
+    fetch = counters(os.path.join(src, "fetch", "fetch_counter_collection.csv"), "FETCH_SIZE")
+    write = counters(os.path.join(src, "write", "write_counter_collection.csv"), "WRITE_SIZE")
+    kernels = {}
+    for k in sorted(set(fetch) | set(write)):
+        fk = sum(fetch.get(k, [0])) / max(1, len(fetch.get(k, [])))
+        wk = sum(write.get(k, [0])) / max(1, len(write.get(k, [])))
+        kernels[k] = {
+            "launches": len(fetch.get(k, [])),
+            "FETCH_SIZE_KiB_mean": round(fk, 1),
+            "WRITE_SIZE_KiB_mean": round(wk, 1),
+            "fetch_bytes_corrected": int(fk * 1024 * 2),
+            "write_bytes": int(wk * 1024),
+            "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024),
+            "avg_launch_ms_kernel_trace": round(avg_ns[k][0] / 1e6, 4) if k in avg_ns else None,
+        }
+    nq = bench["config"]["queries_per_gpu"]
+    red = max(fetch.get("kmx::k_scan_reduce", [0.0]))        # the nq-sized scan; smaller launches belong to the index build
+    fill = next(k for k in kernels if k.startswith("kmx::k_fill<"))
+    out = {
+        "source": f"tools/profile_round.sh {a.tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
+                  "--kernel-trace --stats, each over `python3 bench.py --no-cpu-baseline --no-open-compare --steps 8 --warmup 2`, MI355X",
+        "units": "FETCH_SIZE / WRITE_SIZE are KiB as reported; fetch_bytes_corrected doubles FETCH_SIZE (gfx950 tallies 128-B "
+                 "requests at 64 B, MI355X_MICROARCH.md HBM section); calibration in the same run: the nq-sized k_scan_reduce "
+                 f"reads exactly 4*nq = {4 * nq} B",
+        "bench_value_M_queries_per_s": bench["value"],
+        "kernels": kernels,
+        "calibration_scan_reduce_fetch_ratio": round(red * 1024 / (4.0 * nq), 4),
+        "k_fill": {
+            "kernel": fill,
+            "hbm_bytes_per_launch": kernels[fill]["hbm_bytes_per_launch"],
+            "fetch_bytes_corrected": kernels[fill]["fetch_bytes_corrected"],
+            "write_bytes": kernels[fill]["write_bytes"],
+            "algorithmic_bytes_per_launch": int(bench["roofline"]["algorithmic_bytes_per_launch"]),
+            "avg_launch_ms_kernel_trace": kernels[fill]["avg_launch_ms_kernel_trace"],
+            "avg_launch_ms_bench_hip_events": bench["roofline"]["avg_launch_ms"],
+        },
+    }
+    for name in (f"{a.round}_pmc_summary_{a.tag}.json", "pmc_summary_current.json"):
+        with open(os.path.join(dst, name), "w") as f:
+            json.dump(out, f, indent=1)
+    print(json.dumps(out["k_fill"], indent=1))
+    print("calibration ratio (expect ~0.50):", out["calibration_scan_reduce_fetch_ratio"])
+
+
+if __name__ == "__main__":
+    main()
