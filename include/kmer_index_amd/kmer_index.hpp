@@ -172,6 +172,17 @@ namespace kmer
             return search(hold);
         }
 
+        // kmer_index_element<.., k>::search_k (kmer_index.hpp:183-190): the bucket of the k-mer starting at `it`.
+        // The reference hands out a borrowed pointer to the bucket's vector (nullptr on a miss); here the bucket
+        // arrives as a result whose hits are that bucket (empty on a miss).
+        template<std::size_t k, typename iterator_t>
+        result_t search_k(iterator_t it) const
+        {
+            static_assert(((k == ks) || ...), "search_k<k>: the index holds no element for this k");
+            std::vector<alphabet_t> kmer(it, it + k);
+            return search(kmer);
+        }
+
         const kmx_index* handle() const { return _index.get(); }
     };
 

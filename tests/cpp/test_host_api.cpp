@@ -66,6 +66,13 @@ void run_test(std::size_t text_size, std::uint64_t seed)
         CHECK(single_kmer.search(query).to_vector() == truth);
         CHECK(multi_kmer.search(query).to_vector() == truth);
     }
+    // search_k (kmer_index.hpp:183-190): the bucket of one k-mer, per element of a multi-k index
+    {
+        std::size_t s = (seed * 31337) % (text_size - (k + 2));
+        std::vector<alphabet_t> a(text.begin() + s, text.begin() + s + k), b(text.begin() + s, text.begin() + s + k + 2);
+        CHECK(single_kmer.template search_k<k>(text.begin() + s).to_vector() == naive(text, a));
+        CHECK(multi_kmer.template search_k<k + 2>(text.begin() + s).to_vector() == naive(text, b));
+    }
     // ... and the batch overload
     auto batch = multi_kmer.search(queries);
     CHECK(batch.size() == queries.size());
