@@ -654,12 +654,11 @@ __device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const 
 // k-part + rest) — KMX_VGROUPS queries per wave, one per KMX_VGROUP-lane group, the part's bucket
 // staged in LDS so that the per-candidate binary search runs at LDS latency.  64 candidates = one
 // compressed_bitset word, assembled from KMX_VGROUP-bit slices of the wave's ballots.
-#ifndef KMX_VGROUP
-#define KMX_VGROUP 16
-#endif
+#define KMX_VGROUP 16                            // 32 and 64 lanes per query measured slower
 #define KMX_VGROUPS (KMX_WAVE / KMX_VGROUP)
 #define KMX_VSLICES (64 / KMX_VGROUP)            // ballot slices per mask word
 #define KMX_VSTAGE (1024 / KMX_VGROUPS)          // staged bucket entries per group (4 KB of LDS per wave)
+#define KMX_VCH 8                                // rounds of KMX_VGROUP candidates searched in lockstep
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
                                                         const uint32_t* __restrict__ arena,
                                                         const uint8_t* __restrict__ qranks,
@@ -670,7 +669,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x / KMX_WAVE;
     const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
-    const uint64_t slice_mask = (KMX_VGROUP == 64) ? ~uint64_t(0) : ((uint64_t(1) << (KMX_VGROUP & 63)) - 1);
+    static_assert(KMX_VGROUP == 16 && KMX_VGROUPS == 4, "the mask word assembly below is written for four 16-lane groups");
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
 
@@ -687,38 +686,85 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         const bool fast = have && p1 != ~uint64_t(0);
         const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32);
         const bool staged = fast && pcnt <= KMX_VSTAGE;
-        if (staged)
-            for (uint32_t t = gl; t < pcnt; t += KMX_VGROUP) stage[wv][g][t] = arena[p1src + t];
+        // The staged bucket is padded with 0xFFFFFFFF (never a position) to the wave's largest power of
+        // two, so that the search below is a fixed number of branch-free halving steps for all four groups.
+        uint32_t P = (staged && pcnt > 1) ? (1u << (32 - __clz(int(pcnt - 1)))) : 1u;
+        uint32_t max_it = fast ? (c0 + KMX_VGROUP - 1) / KMX_VGROUP : 0u;
+        const uint32_t n_it = max_it;
+#pragma unroll
+        for (int e = 1; e < KMX_VGROUPS; ++e) {
+            P = max(P, uint32_t(__shfl_xor(int(P), e * KMX_VGROUP)));
+            max_it = max(max_it, uint32_t(__shfl_xor(int(max_it), e * KMX_VGROUP)));
+        }
+        P = uint32_t(__builtin_amdgcn_readfirstlane(int(P)));
+        max_it = uint32_t(__builtin_amdgcn_readfirstlane(int(max_it)));
+        uint32_t* __restrict__ arr = stage[wv][g];
+        {
+            const uint32_t nb = staged ? pcnt : 0u;
+            for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_VGROUP) {     // straight-line loads: dead slots read arena[0]
+                uint32_t v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t t = t0 + uint32_t(j) * KMX_VGROUP + gl;
+                    v[j] = arena[t < nb ? p1src + t : 0];
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t t = t0 + uint32_t(j) * KMX_VGROUP + gl;
+                    if (t < P) arr[t] = t < nb ? v[j] : 0xFFFFFFFFu;
+                }
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        const uint32_t n_it = fast ? (c0 + KMX_VGROUP - 1) / KMX_VGROUP : 0u;
-        uint32_t max_it = n_it;
-        for (int off = 32; off > 0; off >>= 1) max_it = max(max_it, uint32_t(__shfl_xor(int(max_it), off)));
-        uint64_t word = 0;
-        uint32_t valid = 0;
-        for (uint32_t it = 0; it < max_it; ++it) {
-            const uint32_t ci = it * KMX_VGROUP + gl;
-            bool ok = fast && ci < c0;
-            const uint32_t x = (ok ? arena[src + ci] : 0u) + delta;
-            if (staged) {
-                uint32_t lo = 0, hi = pcnt;                             // lower_bound in LDS
-                while (lo < hi) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (stage[wv][g][mid] < x) lo = mid + 1; else hi = mid;
-                }
-                ok = ok && lo < pcnt && stage[wv][g][lo] == x;          // binary_search :283, lower_bound :544-546
-            } else if (ok) {
-                const uint64_t pos = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x);
-                ok = pos < pcnt && arena[p1src + pos] == x;
+        uint32_t w_lo = 0, w_hi = 0, valid = 0;
+        // KMX_VCH rounds of 16 candidates at a time: their loads go out together and their searches advance
+        // in lockstep, so one global and log2(P) + 1 LDS round trips are exposed per chunk instead of per round
+        for (uint32_t it0 = 0; it0 < max_it; it0 += KMX_VCH) {
+            const uint32_t nr = min(uint32_t(KMX_VCH), max_it - it0);  // wave-uniform
+            uint32_t x[KMX_VCH], pos[KMX_VCH], tv[KMX_VCH];
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) {
+                const uint32_t ci = (it0 + uint32_t(r)) * KMX_VGROUP + gl;
+                x[r] = arena[(fast && ci < c0) ? src + ci : 0];        // dead slots read arena[0]
+                pos[r] = 0;
             }
-            const uint64_t bal = __ballot(ok);
-            word |= ((bal >> (KMX_VGROUP * g)) & slice_mask) << (KMX_VGROUP * (it % KMX_VSLICES));
-            if (it < n_it && ((it % KMX_VSLICES) == KMX_VSLICES - 1 || it + 1 == n_it)) {
-                if (gl == 0) words[it / KMX_VSLICES] = word;            // bit i = word i>>6, bit i&63
-                valid += uint32_t(__popcll(word));
-                word = 0;
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) x[r] += delta;
+            for (uint32_t st = P >> 1; st; st >>= 1) {                 // lower_bound (:283 binary_search, :544-546)
+#pragma unroll
+                for (int r = 0; r < KMX_VCH; ++r)
+                    if (uint32_t(r) < nr) tv[r] = arr[pos[r] + st - 1];
+#pragma unroll
+                for (int r = 0; r < KMX_VCH; ++r)
+                    if (uint32_t(r) < nr) pos[r] += tv[r] < x[r] ? st : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r)
+                if (uint32_t(r) < nr) tv[r] = arr[pos[r]];
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) {
+                if (uint32_t(r) >= nr) break;
+                const uint32_t it = it0 + uint32_t(r);
+                bool ok = fast && it * KMX_VGROUP + gl < c0;
+                bool hit = tv[r] == x[r];
+                if (ok && !staged) {                                    // bucket too long for LDS
+                    const uint64_t lb = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x[r]);
+                    hit = lb < pcnt && arena[p1src + lb] == x[r];
+                }
+                ok = ok && hit;
+                // 64 candidates = one bitset word = four rounds of 16-bit ballot slices
+                const uint64_t bal = __ballot(ok);
+                const uint32_t half = (g & 2) ? uint32_t(bal >> 32) : uint32_t(bal);
+                const uint32_t slice = ((half >> ((g & 1) * 16)) & 0xFFFFu) << ((it & 1) * 16);
+                if (it & 2) w_hi |= slice; else w_lo |= slice;
+                if (it < n_it && ((it & 3) == 3 || it + 1 == n_it)) {
+                    if (gl == 0) words[it >> 2] = (uint64_t(w_hi) << 32) | w_lo;   // bit i = word i>>6, bit i&63
+                    valid += uint32_t(__popc(w_lo) + __popc(w_hi));
+                    w_lo = w_hi = 0;
+                }
             }
         }
         if (fast && gl == 0) {
