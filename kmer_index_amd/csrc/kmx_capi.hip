@@ -60,18 +60,33 @@ struct DevBuf {
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Host side of a result: page-locked so that the D2H copies of kmx_result_view run at link speed
+// (pageable malloc memory as the fallback when pinning fails).
 struct HostBuf {
     void* p = nullptr;
     size_t cap = 0;
+    bool pinned = false;
     bool ensure(size_t bytes)
     {
         if (bytes <= cap) return true;
-        free(p);
-        p = malloc(bytes + 64);
+        release();
+        if (bytes >= (size_t(1) << 20) && hipHostMalloc(&p, bytes + 64, hipHostMallocDefault) == hipSuccess) {
+            pinned = true;                                  // small views are not worth a pinning call
+        } else {
+            (void)hipGetLastError();
+            p = malloc(bytes + 64);
+            pinned = false;
+        }
         cap = p ? bytes + 64 : 0;
         return p != nullptr;
     }
-    void release() { free(p); p = nullptr; cap = 0; }
+    void release()
+    {
+        if (p) {
+            if (pinned) (void)hipHostFree(p); else free(p);
+        }
+        p = nullptr; cap = 0; pinned = false;
+    }
     template <typename T> T* as() const { return static_cast<T*>(p); }
 };
 

@@ -156,16 +156,17 @@ class Result:
         _check(lib().kmx_result_counts(self._h, *[C.byref(x) for x in v]))
         return dict(zip(["nq", "n_hits", "n_exact", "n_stitch", "n_prefix", "n_error"], [int(x.value) for x in v]))
 
-    def host(self):
-        """(hit_off[nq+1], positions, status[nq], kinds[nq]) as numpy copies."""
+    def host(self, copy=True):
+        """(hit_off[nq+1], positions, status[nq], kinds[nq]) as numpy arrays: copies, or with copy=False views of the
+        result's own host buffers (valid until the result is searched into again or closed)."""
         c = self.counts()
         a, b, s, k = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
         _check(lib().kmx_result_view(self._h, C.byref(a), C.byref(b), C.byref(s), C.byref(k)))
         nq = c["nq"]
-        hit_off = _view(a.value, nq + 1, np.uint64).copy()
+        hit_off = _view(a.value, nq + 1, np.uint64)
         n_pos = int(hit_off[nq]) if b.value else 0        # positions are NULL for COUNT_ONLY results
-        return (hit_off, _view(b.value, n_pos, np.uint32).copy(), _view(s.value, nq, np.uint8).copy(),
-                _view(k.value, nq, np.uint8).copy())
+        out = (hit_off, _view(b.value, n_pos, np.uint32), _view(s.value, nq, np.uint8), _view(k.value, nq, np.uint8))
+        return tuple(x.copy() for x in out) if copy else out
 
     def device_ptrs(self):
         a, b, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
