@@ -10,7 +10,12 @@ step is collecting results:
   * gather_hit_lists  : the full gatherv of hit_off + positions to one rank (point-to-point
                         send/recv with the displacements from the totals; over xGMI each shard
                         crosses one direct link).
+Replicating the index is either "every rank builds it" (0.1 s on the GPU for 1e8 bp — what bench.py
+does) or build once + broadcast_index: the flat image of kmx_index_save as one broadcast payload.
 """
+import os
+import tempfile
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -49,7 +54,8 @@ def gather_hit_lists(hit_off: torch.Tensor, positions: torch.Tensor, dst: int = 
     device = hit_off.device
     totals = all_gather_totals(hit_off.numel() - 1, positions.numel(), device=device, group=group)
     if rank != dst:
-        dist.send(hit_off[1:].contiguous(), dst=dst, group=group)
+        if hit_off.numel() > 1:
+            dist.send(hit_off[1:].contiguous(), dst=dst, group=group)
         if positions.numel():
             dist.send(positions.contiguous(), dst=dst, group=group)
         return None, None
@@ -73,3 +79,44 @@ def gather_hit_lists(hit_off: torch.Tensor, positions: torch.Tensor, dst: int = 
         q0 += nq_r
         h0 += nh_r
     return g_off, g_pos
+
+
+def broadcast_bytes(data, src: int = 0, device=None, group=None) -> np.ndarray:
+    """One byte string from rank `src` to every rank (length first, then the payload as one broadcast).
+    `data` is bytes / a uint8 array on `src` and ignored elsewhere; every rank returns a uint8 array."""
+    rank = dist.get_rank(group)
+    n = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        payload = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy() if not isinstance(data, np.ndarray) else data)
+        n[0] = payload.numel()
+    dist.broadcast(n, src=src, group=group)
+    if rank != src:
+        payload = torch.empty(int(n.item()), dtype=torch.uint8)
+    payload = payload.to(device) if device is not None else payload
+    if payload.numel():
+        dist.broadcast(payload, src=src, group=group)
+    return payload.cpu().numpy()
+
+
+def broadcast_index(index, src: int = 0, device_index: int = -1, device=None, group=None, scratch_dir=None):
+    """Build once, replicate everywhere: rank `src` passes its engine.Index, every other
+    rank passes None and gets an index loaded from the broadcast image on GPU `device_index`.  `device` is the
+    torch device the collective runs on (a cuda device for the nccl backend, None for gloo)."""
+    from . import engine
+    rank = dist.get_rank(group)
+    scratch_dir = scratch_dir or ("/dev/shm" if os.path.isdir("/dev/shm") else None)
+    fd, path = tempfile.mkstemp(prefix=f"kmx_bcast_r{rank}_", suffix=".img", dir=scratch_dir)
+    os.close(fd)
+    try:
+        image = None
+        if rank == src:
+            index.save(path)
+            image = np.fromfile(path, dtype=np.uint8)
+        image = broadcast_bytes(image, src=src, device=device, group=group)
+        if rank == src:
+            return index
+        image.tofile(path)
+        return engine.Index.load(path, device=device_index)
+    finally:
+        if os.path.exists(path):
+            os.remove(path)

@@ -40,6 +40,16 @@ def _worker(rank, world, port, q):
         t_pos = torch.from_numpy(pos.view(np.int32).copy())
         totals = kdist.all_gather_totals(len(my_off) - 1, pos.size)
         g_off, g_pos = kdist.gather_hit_lists(t_off, t_pos, dst=0)
+        # image transport (broadcast_index's carrier): an odd-sized payload from the last rank, and an empty one
+        blob = np.arange(1_000_003, dtype=np.uint64).astype(np.uint8)
+        got = kdist.broadcast_bytes(blob.tobytes() if rank == world - 1 else None, src=world - 1)
+        assert np.array_equal(got, blob), "broadcast_bytes payload differs"
+        assert kdist.broadcast_bytes(b"" if rank == 0 else None, src=0).size == 0
+        # a rank without queries takes part in the gather
+        e_off, e_pos = kdist.gather_hit_lists(torch.zeros(1 if rank == 1 else 3, dtype=torch.int64) + 0,
+                                              torch.zeros(0, dtype=torch.int32), dst=0)
+        if rank == 0:
+            assert e_off.numel() == 1 + 2 * (world - 1) and e_pos.numel() == 0
         if rank == 0:
             f_off, f_pos, _, _ = oidx.search_batch(qranks, qoff)
             ok = (np.array_equal(g_off.numpy().astype(np.uint64), f_off) and np.array_equal(g_pos.numpy().view(np.uint32), f_pos)
