@@ -169,7 +169,7 @@ struct kmx_result {
     uint64_t n_mask_words = 0;
     // device
     DevBuf src, cnt, c0, aux, key, p1, kind, status, stitch_list, prefix_list, hit_off, bsum, ctr, tile_q, out,
-        mask_words, plen, poff, ptmp, in_qranks, in_qoff;
+        mask_words, stitch_hits, plen, poff, ptmp, in_qranks, in_qoff;
     unsigned long long* h_ctr = nullptr;   // pinned
     // host mirrors
     HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src;
@@ -179,7 +179,7 @@ struct kmx_result {
     void release()
     {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
-                          &tile_q, &out, &mask_words, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
+                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
             b->release();
         for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src})
             b->release();
@@ -723,7 +723,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->ctr.ensure(KMX_CTR_COUNT * sizeof(unsigned long long)));
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
-                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>()};
+                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
     auto* ctr = r->ctr.as<unsigned long long>();
     const KmxIndexDev* dix = ix->d_index;
 
@@ -772,6 +772,12 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
 
     if (r->n_stitch) {
         HIP_TRY(r->mask_words.ensure(r->n_mask_words * 8));
+        // room for every candidate to survive (64 slots per mask word); without it k_compact decodes the masks
+        static const bool no_survivors = getenv("KMX_NO_STITCH_HITS") != nullptr;
+        if (!(flags & KMX_SEARCH_COUNT_ONLY) && !no_survivors && r->stitch_hits.ensure(r->n_mask_words * 64 * 4) == hipSuccess)
+            d.stitch_hits = r->stitch_hits.as<uint32_t>();
+        else
+            (void)hipGetLastError();
         timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, r->n_stitch, r->mask_words.as<uint64_t>()); });
         scan_hits();
         HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -796,7 +802,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
             kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, hit_off, r->tile_q.as<uint32_t>(), ctr + KMX_CTR_TOTAL_HITS, n_tiles, d, out);
         });
     }
-    if (r->n_stitch)
+    if (r->n_stitch && !d.stitch_hits)
         timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
 
     // PREFIX work list: small queries from the front of prefix_list, the others from its back

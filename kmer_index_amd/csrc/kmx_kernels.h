@@ -19,6 +19,8 @@ struct QueryDesc {
     uint8_t* status;        // kmx_query_status
     uint32_t* stitch_list;  // indices of the STITCH queries (arbitrary order)
     uint32_t* prefix_list;  // indices of the PREFIX queries (arbitrary order)
+    uint32_t* stitch_hits;  // STITCH: surviving candidates of query q at [64 * aux[q], 64 * aux[q] + cnt[q]), written by
+                            // k_validate and copied out by k_fill; nullptr -> k_compact decodes the masks instead
 };
 
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,

@@ -645,6 +645,8 @@ __device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const 
         }
         const uint64_t word = __ballot(ok);                        // 64 candidates = one bitset word
         if (lane == 0) words[w] = word;
+        if (ok && d.stitch_hits)
+            d.stitch_hits[d.aux[q] * 64 + valid + uint32_t(__popcll(word & ((uint64_t(1) << lane) - 1)))] = p;
         valid += uint32_t(__popcll(word));
     }
     if (lane == 0) d.cnt[q] = valid;
@@ -682,7 +684,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         const uint64_t src = have ? (d.src[q] & ~SRC_FLAGS) : 0;
         const uint64_t p1 = have ? d.p1[q] : ~uint64_t(0);
         const uint64_t p1src = have ? d.key[q] : 0;
-        uint64_t* __restrict__ words = mask_words + (have ? d.aux[q] : 0);
+        const uint64_t wbase = have ? d.aux[q] : 0;
+        uint64_t* __restrict__ words = mask_words + wbase;
+        const uint64_t sbase = wbase * 64;
         const bool fast = have && p1 != ~uint64_t(0);
         const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32);
         const bool staged = fast && pcnt <= KMX_VSTAGE;
@@ -758,11 +762,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                 // 64 candidates = one bitset word = four rounds of 16-bit ballot slices
                 const uint64_t bal = __ballot(ok);
                 const uint32_t half = (g & 2) ? uint32_t(bal >> 32) : uint32_t(bal);
-                const uint32_t slice = ((half >> ((g & 1) * 16)) & 0xFFFFu) << ((it & 1) * 16);
+                const uint32_t s16 = (half >> ((g & 1) * 16)) & 0xFFFFu;
+                // survivors, already compacted and ascending: what k_fill copies out for this query
+                if (ok && d.stitch_hits) d.stitch_hits[sbase + valid + uint32_t(__popc(s16 & ((1u << gl) - 1u)))] = x[r] - delta;
+                valid += uint32_t(__popc(s16));
+                const uint32_t slice = s16 << ((it & 1) * 16);
                 if (it & 2) w_hi |= slice; else w_lo |= slice;
                 if (it < n_it && ((it & 3) == 3 || it + 1 == n_it)) {
                     if (gl == 0) words[it >> 2] = (uint64_t(w_hi) << 32) | w_lo;   // bit i = word i>>6, bit i&63
-                    valid += uint32_t(__popc(w_lo) + __popc(w_hi));
                     w_lo = w_hi = 0;
                 }
             }
@@ -1078,10 +1085,14 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
     }
     __syncthreads();
 
-    // rare path: PREFIX slots (dependent loads) and STITCH slots (left to k_compact)
+    // rare path: PREFIX slots (dependent loads) and STITCH slots (the survivors of k_validate)
     auto slow_slot = [&](uint32_t slot, rec_t v, bool& live) -> uint32_t {
         const uint64_t q = uint64_t(qa) + uint64_t(v & ~SLOW);
-        if (d.kind[q] != KMX_KIND_PREFIX) { live = false; return 0; }
+        if (d.kind[q] != KMX_KIND_PREFIX) {
+            // STITCH: the survivors k_validate left behind, or (no survivor buffer) nothing — k_compact writes the slot
+            if (!d.stitch_hits) { live = false; return 0; }
+            return d.stitch_hits[d.aux[q] * 64 + (base + slot - hit_off[q])];
+        }
         // slice of every k-mer with this prefix, then the last-kmer offsets
         // (kmer_index.hpp:138-146): bit j of aux <-> position n - j
         const uint64_t idx = base + slot - hit_off[q];
