@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -80,6 +81,15 @@ struct HostBuf {
         cap = p ? bytes + 64 : 0;
         return p != nullptr;
     }
+    bool ensure_pinned(size_t bytes)                        // page-locked or nothing
+    {
+        if (bytes <= cap && pinned) return true;
+        release();
+        if (hipHostMalloc(&p, bytes + 64, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        pinned = true;
+        cap = bytes + 64;
+        return true;
+    }
     void release()
     {
         if (p) {
@@ -136,7 +146,21 @@ struct Stats {
 
 } // namespace
 
+// Results released with kmx_result_free wait here for the next search that arrives without a result of its
+// own: a fresh result costs some twenty device allocations, which dominates the latency of small batches
+// (kmer_index::search(query) is a batch of one).  Shared between the index and its results, so a result may
+// outlive its index.
+struct ResultPool {
+    std::mutex mu;
+    std::vector<kmx_result*> idle;
+    bool closed = false;
+};
+constexpr size_t kPoolMaxResults = 8;
+constexpr size_t kPoolMaxBytes = size_t(256) << 20;     // larger results give their memory back at once
+constexpr size_t kSmallView = size_t(256) << 10;        // host views up to this size: one page-locked block, one wait
+
 struct kmx_index {
+    std::shared_ptr<ResultPool> pool = std::make_shared<ResultPool>();
     int device = 0;
     uint64_t n = 0;
     uint32_t sigma = 0;
@@ -172,16 +196,28 @@ struct kmx_result {
         mask_words, stitch_hits, plen, poff, ptmp, in_qranks, in_qoff;
     unsigned long long* h_ctr = nullptr;   // pinned
     // host mirrors
-    HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src;
+    HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src, h_small;
+    uint64_t* v_hit_off = nullptr; uint32_t* v_positions = nullptr; uint8_t* v_status = nullptr; uint8_t* v_kinds = nullptr;   // the current host view
     bool host_valid = false, host_masks_valid = false;
     bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
+    std::shared_ptr<ResultPool> pool;      // where kmx_result_free parks this result (set by the search that made it)
+    bool quiesced = true;                  // no kernel of the last search can still be running on `stream`
+
+    size_t device_bytes() const
+    {
+        size_t b = 0;
+        for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
+                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
+            b += d->cap;
+        return b;
+    }
 
     void release()
     {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
                           &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
             b->release();
-        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src})
+        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small})
             b->release();
         if (h_ctr) (void)hipHostFree(h_ctr);
         h_ctr = nullptr;
@@ -189,6 +225,18 @@ struct kmx_result {
 };
 
 namespace {
+
+kmx_result* take_result(kmx_index* ix)
+{
+    kmx_result* r = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(ix->pool->mu);
+        if (!ix->pool->idle.empty()) { r = ix->pool->idle.back(); ix->pool->idle.pop_back(); }
+    }
+    if (!r) r = new kmx_result();
+    r->pool = ix->pool;
+    return r;
+}
 
 template <typename F>
 void timed(kmx_index* ix, int id, hipStream_t s, F&& launch)
@@ -597,6 +645,15 @@ void kmx_index_free(kmx_index* ix)
 {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    {
+        std::vector<kmx_result*> idle;
+        {
+            std::lock_guard<std::mutex> lock(ix->pool->mu);
+            ix->pool->closed = true;
+            idle.swap(ix->pool->idle);
+        }
+        for (kmx_result* r : idle) { r->release(); delete r; }
+    }
     ix->stats.destroy();
     if (ix->stream) (void)hipStreamDestroy(ix->stream);
     for (void* p : ix->allocs) (void)hipFree(p);
@@ -694,7 +751,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     const uint64_t* qo = static_cast<const uint64_t*>(d_qoff);
 
     kmx_result* r = *inout;
-    if (!r) { r = new kmx_result(); *inout = r; }
+    if (!r) { r = take_result(ix); *inout = r; }
     r->index = ix;
     r->device = ix->device;
     r->stream = s;
@@ -703,6 +760,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     r->nq = nq;
     r->n_hits = r->n_exact = r->n_stitch = r->n_prefix = r->n_error = r->n_none = r->n_mask_words = 0;
     r->host_valid = r->host_masks_valid = false;
+    r->quiesced = false;
     if (!r->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->h_ctr), KMX_CTR_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(r->hit_off.ensure((nq + 1) * 8));
     if (nq == 0) {
@@ -854,7 +912,7 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     kmx_index* ix = const_cast<kmx_index*>(cix);
     std::lock_guard<std::mutex> lock(ix->host_call_mu);
     HIP_TRY(hipSetDevice(ix->device));
-    kmx_result* r = *out ? *out : new kmx_result();
+    kmx_result* r = *out ? *out : take_result(ix);
     *out = r;
     const uint64_t n_letters = nq ? qoff[nq] : 0;
     HIP_TRY(r->in_qranks.ensure(std::max<uint64_t>(n_letters, 1)));
@@ -864,6 +922,7 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     kmx_status st = kmx_search_batch_device(ix, r->in_qranks.p, r->in_qoff.p, nq, flags, ix->stream, out);
     if (st != KMX_OK) return st;
     HIP_TRY(hipStreamSynchronize(ix->stream));
+    r->quiesced = true;
     return KMX_OK;
 }
 
@@ -896,23 +955,46 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view: result is NULL");
     if (!r->host_valid) {
         HIP_TRY(hipSetDevice(r->device));
-        HIP_TRY(hipStreamSynchronize(r->stream));
         const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
-        if (!r->h_hit_off.ensure((r->nq + 1) * 8) || !r->h_status.ensure(std::max<uint64_t>(r->nq, 1)) ||
-            !r->h_kinds.ensure(std::max<uint64_t>(r->nq, 1)) || !r->h_positions.ensure(std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
-            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_view: host allocation failed");
-        HIP_TRY(hipMemcpy(r->h_hit_off.p, r->hit_off.p, (r->nq + 1) * 8, hipMemcpyDeviceToHost));
-        if (r->nq) {
-            HIP_TRY(hipMemcpy(r->h_status.p, r->status.p, r->nq, hipMemcpyDeviceToHost));
-            HIP_TRY(hipMemcpy(r->h_kinds.p, r->kind.p, r->nq, hipMemcpyDeviceToHost));
+        const size_t b_off = (r->nq + 1) * 8, b_pos = have_pos ? r->n_hits * 4 : 0, b_st = r->nq;
+        const size_t small_total = b_off + ((b_pos + 7) & ~size_t(7)) + 2 * ((b_st + 7) & ~size_t(7));
+        if (small_total <= kSmallView && r->h_small.ensure_pinned(kSmallView)) {
+            // small result: the four arrays share one page-locked block, four async copies, one wait
+            char* base = r->h_small.as<char>();
+            r->v_hit_off = reinterpret_cast<uint64_t*>(base);
+            r->v_positions = reinterpret_cast<uint32_t*>(base + b_off);
+            r->v_status = reinterpret_cast<uint8_t*>(base + b_off + ((b_pos + 7) & ~size_t(7)));
+            r->v_kinds = r->v_status + ((b_st + 7) & ~size_t(7));
+            HIP_TRY(hipMemcpyAsync(r->v_hit_off, r->hit_off.p, b_off, hipMemcpyDeviceToHost, r->stream));
+            if (r->nq) {
+                HIP_TRY(hipMemcpyAsync(r->v_status, r->status.p, r->nq, hipMemcpyDeviceToHost, r->stream));
+                HIP_TRY(hipMemcpyAsync(r->v_kinds, r->kind.p, r->nq, hipMemcpyDeviceToHost, r->stream));
+            }
+            if (have_pos) HIP_TRY(hipMemcpyAsync(r->v_positions, r->out.p, b_pos, hipMemcpyDeviceToHost, r->stream));
+            HIP_TRY(hipStreamSynchronize(r->stream));
+        } else {
+            HIP_TRY(hipStreamSynchronize(r->stream));
+            if (!r->h_hit_off.ensure(b_off) || !r->h_status.ensure(std::max<uint64_t>(r->nq, 1)) ||
+                !r->h_kinds.ensure(std::max<uint64_t>(r->nq, 1)) || !r->h_positions.ensure(std::max<uint64_t>(b_pos, 4)))
+                return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_view: host allocation failed");
+            r->v_hit_off = r->h_hit_off.as<uint64_t>();
+            r->v_positions = r->h_positions.as<uint32_t>();
+            r->v_status = r->h_status.as<uint8_t>();
+            r->v_kinds = r->h_kinds.as<uint8_t>();
+            HIP_TRY(hipMemcpy(r->v_hit_off, r->hit_off.p, b_off, hipMemcpyDeviceToHost));
+            if (r->nq) {
+                HIP_TRY(hipMemcpy(r->v_status, r->status.p, r->nq, hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(r->v_kinds, r->kind.p, r->nq, hipMemcpyDeviceToHost));
+            }
+            if (have_pos) HIP_TRY(hipMemcpy(r->v_positions, r->out.p, b_pos, hipMemcpyDeviceToHost));
         }
-        if (have_pos) HIP_TRY(hipMemcpy(r->h_positions.p, r->out.p, r->n_hits * 4, hipMemcpyDeviceToHost));
+        r->quiesced = true;
         r->host_valid = true;
     }
-    if (hit_off) *hit_off = r->h_hit_off.as<uint64_t>();
-    if (positions) *positions = ((r->flags & KMX_SEARCH_COUNT_ONLY) || !r->n_hits) ? nullptr : r->h_positions.as<uint32_t>();
-    if (status) *status = r->h_status.as<uint8_t>();
-    if (kinds) *kinds = r->h_kinds.as<uint8_t>();
+    if (hit_off) *hit_off = r->v_hit_off;
+    if (positions) *positions = ((r->flags & KMX_SEARCH_COUNT_ONLY) || !r->n_hits) ? nullptr : r->v_positions;
+    if (status) *status = r->v_status;
+    if (kinds) *kinds = r->v_kinds;
     return KMX_OK;
 }
 
@@ -947,6 +1029,18 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
 void kmx_result_free(kmx_result* r)
 {
     if (!r) return;
+    if (r->pool && r->device_bytes() <= kPoolMaxBytes) {
+        if (!r->quiesced) {                                  // its buffers are about to serve another stream
+            (void)hipSetDevice(r->device);
+            (void)hipDeviceSynchronize();
+            r->quiesced = true;
+        }
+        std::lock_guard<std::mutex> lock(r->pool->mu);
+        if (!r->pool->closed && r->pool->idle.size() < kPoolMaxResults) {
+            r->pool->idle.push_back(r);
+            return;
+        }
+    }
     if (r->index) (void)hipSetDevice(r->device);
     r->release();
     delete r;
