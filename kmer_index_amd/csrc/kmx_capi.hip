@@ -832,11 +832,12 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         HIP_TRY(r->mask_words.ensure(r->n_mask_words * 8));
         // room for every candidate to survive (64 slots per mask word); without it k_compact decodes the masks
         static const bool no_survivors = getenv("KMX_NO_STITCH_HITS") != nullptr;
-        if (!(flags & KMX_SEARCH_COUNT_ONLY) && !no_survivors && r->stitch_hits.ensure(r->n_mask_words * 64 * 4) == hipSuccess)
+        const uint64_t n_more = r->h_ctr[KMX_CTR_STITCH_MORE];   // queries whose survivors need their further parts checked
+        if ((!(flags & KMX_SEARCH_COUNT_ONLY) || n_more) && !no_survivors && r->stitch_hits.ensure(r->n_mask_words * 64 * 4) == hipSuccess)
             d.stitch_hits = r->stitch_hits.as<uint32_t>();
         else
             (void)hipGetLastError();
-        timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, r->n_stitch, r->mask_words.as<uint64_t>()); });
+        timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, r->n_stitch, n_more, r->mask_words.as<uint64_t>()); });
         scan_hits();
         HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));

@@ -13,8 +13,8 @@ struct QueryDesc {
     uint32_t* cnt;          // number of hits (STITCH: written by k_validate)
     uint32_t* c0;           // STITCH: number of candidates; PREFIX: number of runs in the slice
     uint64_t* aux;          // STITCH: index of the first mask word; PREFIX: last-kmer bits (bit j <-> position n-j)
-    uint64_t* key;          // PREFIX: key index of the first run (offs + key bounds the runs); STITCH: arena index of the single further part's bucket
-    uint64_t* p1;           // STITCH: (offset of the single further part in the query << 32) | its bucket size, ~0 when there are several
+    uint64_t* key;          // PREFIX: key index of the first run (offs + key bounds the runs); STITCH: arena index of that further part's bucket
+    uint64_t* p1;           // STITCH: one further part, (its offset in the query << 32) | its bucket size; bit 63: more parts follow
     uint8_t* kind;          // kmx_query_kind
     uint8_t* status;        // kmx_query_status
     uint32_t* stitch_list;  // indices of the STITCH queries (arbitrary order)
@@ -26,7 +26,7 @@ struct QueryDesc {
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr);
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
-                     const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words);
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);
 void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
                  unsigned long long* total_out);

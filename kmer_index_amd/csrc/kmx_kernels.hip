@@ -39,6 +39,7 @@ namespace kmx {
 // last-kmer positions behind the slice take the per-slot path
 #define SRC_PREFIX (uint64_t(1) << 62)
 #define SRC_FLAGS (SRC_SLOW | SRC_PREFIX)
+#define KMX_P1_MORE (uint64_t(1) << 63)    // QueryDesc::p1: the query has further parts beyond the one p1 names
 
 // ---------------------------------------------------------------------------
 // small device helpers
@@ -195,7 +196,7 @@ __device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_prefix, n_prefix_big, n_error, n_none;
+    unsigned int n_stitch, n_prefix, n_prefix_big, n_error, n_none, n_more;
     unsigned long long words, pelems;
     unsigned int max_runs;
     unsigned int base_stitch, base_prefix, base_prefix_big;
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = 0;
+        bc.n_stitch = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = 0;
         bc.max_runs = 0;
     }
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
     uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
     uint64_t src = 0, aux = 0, key = 0;
-    uint64_t p1 = ~uint64_t(0);   // STITCH with exactly one further part: (offset in query << 32) | bucket size, bucket in `key`
+    uint64_t p1 = 0;              // STITCH: one further part as (offset in query << 32) | bucket size, bucket in `key`; bit 63: more parts follow
     uint32_t cnt = 0, c0 = 0;
     unsigned int my_stitch = 0, my_prefix = 0;
     unsigned long long my_words = 0;
@@ -430,7 +431,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                             }
                             if (all && ranks_ok) {
                                 kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
-                                if (P - 1 + (rest ? 1 : 0) == 1) { key = extra.src; p1 = (uint64_t(extra_delta) << 32) | extra.cnt; }
+                                key = extra.src;
+                                p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (P - 1 + (rest ? 1 : 0) > 1 ? KMX_P1_MORE : 0);
                             }
                         }
                     }
@@ -458,7 +460,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                     if (nparts == 1) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }   // :529-530
                     else {
                         kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
-                        if (nparts == 2) { key = extra.src; p1 = (uint64_t(extra_delta) << 32) | extra.cnt; }
+                        key = extra.src;
+                        p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (nparts > 2 ? KMX_P1_MORE : 0);
                     }
                 }
             }
@@ -474,6 +477,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     unsigned int loc = 0;
     unsigned long long loc_words = 0;
     if (my_stitch) {
+        if (p1 & KMX_P1_MORE) atomicAdd(&bc.n_more, 1u);
         loc = atomicAdd(&bc.n_stitch, 1u);
         loc_words = atomicAdd(&bc.words, my_words);
     }
@@ -516,6 +520,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         if (bc.n_stitch) {
             bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
             bc.base_words = atomicAdd(&ctr[KMX_CTR_MASK_WORDS], bc.words);
+            if (bc.n_more) atomicAdd(&ctr[KMX_CTR_STITCH_MORE], (unsigned long long)bc.n_more);
         }
         if (bc.n_prefix) bc.base_prefix = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX], (unsigned long long)bc.n_prefix);
         if (bc.n_prefix_big) {
@@ -541,7 +546,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 }
 
 // ---------------------------------------------------------------------------
-// k_validate — one wave per STITCH query.
+// k_validate — STITCH queries.
 //
 // Candidates are the positions of the first part's bucket (kmer_index.hpp:272,
 // :532).  Candidate p survives when, for every further part j that starts at
@@ -549,118 +554,74 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 // A rest that is shorter than k (:230-256) is checked through the k-mer that ends
 // the query (offset m - k) instead of through the sigma^(k-rest) prefix buckets:
 // both decide "the text continues with the rest of the query at p + P*k".
-// 64 candidates = one compressed_bitset word, produced by one ballot.
+//
+// KMX_VGROUPS queries per wave, one per KMX_VGROUP-lane group.  Every STITCH query names one further part
+// (QueryDesc::key / p1): its bucket is staged in LDS and filters all candidates at LDS latency.  A query with
+// more parts than that checks them for the survivors of the filter only — they are few: a candidate passes
+// by chance with probability bucket/n — one part per lane of the group.  64 candidates = one
+// compressed_bitset word, assembled from 16-bit slices of the wave's ballots.
 // ---------------------------------------------------------------------------
-// General STITCH query (any number of parts), one wave per query.
-__device__ void validate_general_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
-                                      const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff,
-                                      const QueryDesc& d, uint32_t q, uint64_t* __restrict__ mask_words)
-{
-    const uint32_t lane = lane_id();
-    const uint32_t sigma = ix->sigma;
-    const uint32_t c0 = d.c0[q];
-    const uint64_t src = d.src[q] & ~SRC_FLAGS;
-    uint64_t* __restrict__ words = mask_words + d.aux[q];
-    const uint32_t n_words = c0 / 64 + 1;                              // compressed_bitset.hpp:23
-    const uint64_t b = qoff[q];
-    const uint64_t m = qoff[q + 1] - b;
-    const uint8_t* __restrict__ qr = qranks + b;
-    const uint8_t* __restrict__ qend = qr + m;                         // wide letter loads stay inside this query
-    const KmxPlanEntry pe = load_plan(ix, m);
-
-    // parts beyond the first one
-    uint32_t n_extra, sk = 0, sP = 0;
-    const KmxElemDev* __restrict__ sel = nullptr;
-    if (pe.scheme == KMX_SCHEME_SINGLE) {
-        sel = &ix->elems[pe.elem];
-        sk = sel->k;
-        sP = uint32_t(m / sk);
-        n_extra = sP - 1 + ((m % sk) ? 1 : 0);
-    } else {
-        n_extra = pe.nparts - 1u;
-    }
-
-    // lane = part: (bucket, offset of the part inside the query)
-    uint64_t p_src = 0;
-    uint32_t p_cnt = 0, p_delta = 0;
-    uint64_t mm = m;   // multi scheme: cursor of the walk over _optimal_nk_sum[m], last summand first
-    auto load_parts = [&](uint32_t base_part, uint32_t chunk) {
-        if (pe.scheme == KMX_SCHEME_SINGLE) {
-            if (lane < chunk) {
-                const uint32_t part = base_part + lane;
-                // j = 1 .. P-1 at j*k (:279-291), then, for a rest, the k-mer that ends the query
-                const uint64_t start = (part < sP - 1) ? uint64_t(part + 1) * sk : (m - sk);
-                uint64_t h;
-                rank_hash(qr + start, sk, sigma, h, qend);
-                const Run r = probe(sel, h);
-                p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(start);
-            }
-        } else {
-            // the walk is serial and wave-uniform; lane s keeps step s
-            for (uint32_t s = 0; s < chunk; ++s) {
-                const KmxPlanEntry e = load_plan(ix, mm);
-                const KmxElemDev* __restrict__ el = &ix->elems[e.elem];
-                const uint32_t k = el->k;
-                mm -= k;                                           // this summand covers [mm, mm + k)
-                if (lane == s) {
-                    uint64_t h;
-                    rank_hash(qr + mm, k, sigma, h, qend);
-                    const Run r = probe(el, h);                    // search_k, :520
-                    p_src = r.src; p_cnt = r.cnt; p_delta = uint32_t(mm);
-                }
-            }
-        }
-    };
-    auto check_parts = [&](uint32_t chunk, uint32_t p, bool ok) -> bool {
-        for (uint32_t s = 0; s < chunk; ++s) {
-            const uint64_t bs = __shfl(p_src, int(s));
-            const uint32_t bn = __shfl(p_cnt, int(s));
-            const uint32_t dl = __shfl(p_delta, int(s));
-            if (ok) {
-                const uint32_t x = p + dl;
-                const uint64_t pos = lower_bound_dev<uint32_t>(arena + bs, bn, x);
-                ok = pos < bn && arena[bs + pos] == x;             // binary_search :283, lower_bound :544-546
-            }
-            if (!__any(ok)) break;
-        }
-        return ok;
-    };
-
-    const bool one_chunk = n_extra <= KMX_WAVE;
-    if (one_chunk) load_parts(0, n_extra);
-    uint32_t valid = 0;
-    for (uint32_t w = 0; w < n_words; ++w) {
-        const uint32_t ci = w * 64 + lane;
-        bool ok = ci < c0;
-        const uint32_t p = ok ? arena[src + ci] : 0;
-        if (one_chunk) {
-            ok = check_parts(n_extra, p, ok);
-        } else {
-            mm = m;
-            for (uint32_t base_part = 0; base_part < n_extra && __any(ok); base_part += KMX_WAVE) {
-                const uint32_t chunk = min(uint32_t(KMX_WAVE), n_extra - base_part);
-                load_parts(base_part, chunk);
-                ok = check_parts(chunk, p, ok);
-            }
-        }
-        const uint64_t word = __ballot(ok);                        // 64 candidates = one bitset word
-        if (lane == 0) words[w] = word;
-        if (ok && d.stitch_hits)
-            d.stitch_hits[d.aux[q] * 64 + valid + uint32_t(__popcll(word & ((uint64_t(1) << lane) - 1)))] = p;
-        valid += uint32_t(__popcll(word));
-    }
-    if (lane == 0) d.cnt[q] = valid;
-}
-
-// Fast path: STITCH queries with exactly one further part (2 multi-k summands, 2 k-parts, or one
-// k-part + rest) — KMX_VGROUPS queries per wave, one per KMX_VGROUP-lane group, the part's bucket
-// staged in LDS so that the per-candidate binary search runs at LDS latency.  64 candidates = one
-// compressed_bitset word, assembled from KMX_VGROUP-bit slices of the wave's ballots.
 #define KMX_VGROUP 16                            // 32 and 64 lanes per query measured slower
 #define KMX_VGROUPS (KMX_WAVE / KMX_VGROUP)
 #define KMX_VSLICES (64 / KMX_VGROUP)            // ballot slices per mask word
 #define KMX_VSTAGE (1024 / KMX_VGROUPS)          // staged bucket entries per group (4 KB of LDS per wave)
 #define KMX_VCH 8                                // rounds of KMX_VGROUP candidates searched in lockstep
+// Does candidate position p continue with every further part of query q?  Called by a whole KMX_VGROUP-lane
+// group (gl = lane in group); lane gl takes parts gl, gl + 16, ...  Part e of a single-k query: the k-part at
+// (e + 1) * k (:279-291), last the k-mer that ends the query when there is a rest; of a multi-k query: the
+// e-th summand of _optimal_nk_sum[m] counted from the end (:532-555).  Returns this lane's verdict.
+__device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
+                                                  const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff,
+                                                  uint32_t q, uint32_t p, uint32_t gl)
+{
+    const uint64_t b = qoff[q];
+    const uint64_t m = qoff[q + 1] - b;
+    const uint8_t* __restrict__ qr = qranks + b;
+    const uint8_t* __restrict__ qend = qranks + qoff[q + 1];
+    const uint32_t sigma = ix->sigma;
+    const KmxPlanEntry pe = load_plan(ix, m);
+    bool good = true;
+    if (pe.scheme == KMX_SCHEME_SINGLE) {
+        const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
+        const uint32_t k = el->k;
+        const uint32_t P = uint32_t(m / k);
+        const uint32_t n_extra = P - 1 + ((m % k) ? 1 : 0);
+        for (uint32_t e = gl; e < n_extra && good; e += KMX_VGROUP) {
+            const uint64_t start = (e < P - 1) ? uint64_t(e + 1) * k : (m - k);
+            uint64_t h;
+            rank_hash(qr + start, k, sigma, h, qend);
+            const Run r = probe(el, h);
+            const uint32_t x = p + uint32_t(start);
+            const uint64_t lb = lower_bound_dev<uint32_t>(arena + r.src, r.cnt, x);
+            good = lb < r.cnt && arena[r.src + lb] == x;              // binary_search :283
+        }
+    } else {
+        const uint32_t n_extra = pe.nparts - 1u;
+        uint64_t mm = m;                                               // the walk resumes where this lane stopped
+        uint32_t walked = 0;
+        for (uint32_t e = gl; e < n_extra && good; e += KMX_VGROUP) {
+            const KmxElemDev* __restrict__ el = nullptr;
+            uint32_t k = 0;
+            for (; walked <= e; ++walked) {
+                const KmxPlanEntry en = load_plan(ix, mm);
+                el = &ix->elems[en.elem];
+                k = el->k;
+                mm -= k;                                               // this summand covers [mm, mm + k)
+            }
+            uint64_t h;
+            rank_hash(qr + mm, k, sigma, h, qend);
+            const Run r = probe(el, h);                                // search_k, :520
+            const uint32_t x = p + uint32_t(mm);
+            const uint64_t lb = lower_bound_dev<uint32_t>(arena + r.src, r.cnt, x);
+            good = lb < r.cnt && arena[r.src + lb] == x;              // lower_bound :544-546
+        }
+    }
+    return good;
+}
+
+// INLINE_MORE: the survivors' further parts are checked right here (more registers, and the groups of a wave wait
+// for each other's survivors); otherwise k_validate_more does it afterwards from the survivor lists.
+template <bool INLINE_MORE>
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
                                                         const uint32_t* __restrict__ arena,
                                                         const uint8_t* __restrict__ qranks,
@@ -682,13 +643,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         // one round of independent loads per group
         const uint32_t c0 = have ? d.c0[q] : 0u;
         const uint64_t src = have ? (d.src[q] & ~SRC_FLAGS) : 0;
-        const uint64_t p1 = have ? d.p1[q] : ~uint64_t(0);
+        const uint64_t p1 = have ? d.p1[q] : 0;
         const uint64_t p1src = have ? d.key[q] : 0;
         const uint64_t wbase = have ? d.aux[q] : 0;
         uint64_t* __restrict__ words = mask_words + wbase;
         const uint64_t sbase = wbase * 64;
-        const bool fast = have && p1 != ~uint64_t(0);
-        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32);
+        const bool fast = have;
+        const bool more = INLINE_MORE && (p1 & KMX_P1_MORE) != 0;
+        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & 0x7FFFFFFFu;
         const bool staged = fast && pcnt <= KMX_VSTAGE;
         // The staged bucket is padded with 0xFFFFFFFF (never a position) to the wave's largest power of
         // two, so that the search below is a fixed number of branch-free halving steps for all four groups.
@@ -748,23 +710,49 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
 #pragma unroll
             for (int r = 0; r < KMX_VCH; ++r)
                 if (uint32_t(r) < nr) tv[r] = arr[pos[r]];
+            uint32_t okm = 0;                                           // bit r: this lane's candidate of round r holds so far
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) {
+                if (uint32_t(r) >= nr) break;
+                const bool live = fast && (it0 + uint32_t(r)) * KMX_VGROUP + gl < c0;
+                bool hit = tv[r] == x[r];
+                if (live && !staged) {                                  // bucket too long for LDS
+                    const uint64_t lb = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x[r]);
+                    hit = lb < pcnt && arena[p1src + lb] == x[r];
+                }
+                okm |= uint32_t(live && hit) << r;
+            }
+            if (INLINE_MORE && __any(more && okm != 0)) {
+                // queries with further parts: the survivors of the filter, one per group at a time
+#pragma unroll 1
+                for (uint32_t r = 0; r < nr; ++r) {
+                    uint32_t pend = uint32_t(__ballot(more && ((okm >> r) & 1u)) >> (KMX_VGROUP * g)) & 0xFFFFu;   // group-uniform
+                    uint32_t dropped = 0;
+                    while (__any(pend != 0)) {
+                        if (pend) {
+                            const uint32_t bsel = uint32_t(__ffs(int(pend))) - 1u;
+                            const uint32_t pc = arena[src + uint64_t(it0 + r) * KMX_VGROUP + bsel];
+                            const bool good = stitch_parts_hold(ix, arena, qranks, qoff, q, pc, gl);
+                            const uint32_t verdicts = uint32_t(__ballot(good) >> (KMX_VGROUP * g)) & 0xFFFFu;
+                            if (verdicts != 0xFFFFu) dropped |= 1u << bsel;
+                            pend &= pend - 1;
+                        }
+                    }
+                    if ((dropped >> gl) & 1u) okm &= ~(1u << r);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < KMX_VCH; ++r) {
                 if (uint32_t(r) >= nr) break;
                 const uint32_t it = it0 + uint32_t(r);
-                bool ok = fast && it * KMX_VGROUP + gl < c0;
-                bool hit = tv[r] == x[r];
-                if (ok && !staged) {                                    // bucket too long for LDS
-                    const uint64_t lb = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x[r]);
-                    hit = lb < pcnt && arena[p1src + lb] == x[r];
-                }
-                ok = ok && hit;
+                const bool ok = (okm >> r) & 1u;
                 // 64 candidates = one bitset word = four rounds of 16-bit ballot slices
                 const uint64_t bal = __ballot(ok);
                 const uint32_t half = (g & 2) ? uint32_t(bal >> 32) : uint32_t(bal);
                 const uint32_t s16 = (half >> ((g & 1) * 16)) & 0xFFFFu;
                 // survivors, already compacted and ascending: what k_fill copies out for this query
-                if (ok && d.stitch_hits) d.stitch_hits[sbase + valid + uint32_t(__popc(s16 & ((1u << gl) - 1u)))] = x[r] - delta;
+                if (ok && d.stitch_hits)
+                    d.stitch_hits[sbase + valid + uint32_t(__popc(s16 & ((1u << gl) - 1u)))] = arena[src + uint64_t(it) * KMX_VGROUP + gl];
                 valid += uint32_t(__popc(s16));
                 const uint32_t slice = s16 << ((it & 1) * 16);
                 if (it & 2) w_hi |= slice; else w_lo |= slice;
@@ -780,12 +768,54 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         }
         __builtin_amdgcn_wave_barrier();                                // stage[] is reused by the next round
 
-        // queries with more parts: the whole wave serves them one at a time
-        for (uint32_t e = 0; e < KMX_VGROUPS; ++e) {
-            const uint32_t qe = __shfl(q, int(e * KMX_VGROUP));
-            const int general = __shfl(int(have && !fast), int(e * KMX_VGROUP));
-            if (general) validate_general_wave(ix, arena, qranks, qoff, d, qe, mask_words);
+    }
+}
+
+// k_validate_more — STITCH queries with further parts beyond the filter of k_validate<false>: every survivor
+// the filter left in stitch_hits is checked against all parts (one part per lane of the query's group);
+// the list is compacted in place, the mask bit of a dropped survivor is cleared and cnt is corrected.
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate_more(const KmxIndexDev* __restrict__ ix,
+                                                             const uint32_t* __restrict__ arena,
+                                                             const uint8_t* __restrict__ qranks,
+                                                             const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                             uint64_t n_stitch, uint64_t* __restrict__ mask_words)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
+        const uint64_t i = i0 + g;
+        const bool have = i < n_stitch;
+        const uint32_t q = have ? d.stitch_list[i] : 0u;
+        const uint64_t p1 = have ? d.p1[q] : 0;
+        const uint32_t tentative = have ? d.cnt[q] : 0u;
+        const bool active = (p1 & KMX_P1_MORE) != 0 && tentative != 0;     // group-uniform
+        uint32_t rounds = active ? tentative : 0u;
+#pragma unroll
+        for (int e = 1; e < KMX_VGROUPS; ++e) rounds = max(rounds, uint32_t(__shfl_xor(int(rounds), e * KMX_VGROUP)));
+        rounds = uint32_t(__builtin_amdgcn_readfirstlane(int(rounds)));
+        if (rounds == 0) continue;
+        const uint64_t wbase = active ? d.aux[q] : 0;
+        uint32_t* __restrict__ hits = d.stitch_hits + wbase * 64;
+        uint32_t kept = 0;
+        for (uint32_t t = 0; t < rounds; ++t) {
+            if (active && t < tentative) {
+                const uint32_t p = hits[t];
+                const bool good = stitch_parts_hold(ix, arena, qranks, qoff, q, p, gl);
+                const uint32_t verdicts = uint32_t(__ballot(good) >> (KMX_VGROUP * g)) & 0xFFFFu;
+                if (verdicts == 0xFFFFu) {
+                    if (gl == 0 && kept != t) hits[kept] = p;
+                    ++kept;
+                } else if (gl == 0) {
+                    // the candidates are ascending: the survivor's index is its rank in the first part's bucket
+                    const uint64_t src = d.src[q] & ~SRC_FLAGS;
+                    const uint64_t idx = lower_bound_dev<uint32_t>(arena + src, d.c0[q], p);
+                    mask_words[wbase + (idx >> 6)] &= ~(uint64_t(1) << (idx & 63));
+                }
+            }
         }
+        if (active && gl == 0) d.cnt[q] = kept;
     }
 }
 
@@ -1347,12 +1377,20 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
     hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
 }
 
+// n_more = STITCH queries with further parts beyond the filter part.  With a survivor buffer (d.stitch_hits) those are
+// finished by k_validate_more from the survivor lists; without one k_validate checks them in line.
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
-                     const QueryDesc& d, uint64_t n_stitch, uint64_t* mask_words)
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t* mask_words)
 {
     uint64_t waves = (n_stitch + KMX_VGROUPS - 1) / KMX_VGROUPS;        // KMX_VGROUPS queries per wave
     unsigned int blocks = (unsigned int)std::min<uint64_t>((waves + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_validate, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
+    const dim3 grid(blocks ? blocks : 1), block(KMX_BLOCK);
+    if (n_more && !d.stitch_hits) {
+        hipLaunchKernelGGL(k_validate<true>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
+        return;
+    }
+    hipLaunchKernelGGL(k_validate<false>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
+    if (n_more) hipLaunchKernelGGL(k_validate_more, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
 }
 
 uint64_t scan_blocks(uint64_t n) { return blocks_for(n, KMX_SCAN_TILE); }

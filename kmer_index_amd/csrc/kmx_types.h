@@ -92,6 +92,7 @@ enum {
     KMX_CTR_TOTAL_HITS = 7,   // written by the scan
     KMX_CTR_NONE = 8,         // valid queries without a hit
     KMX_CTR_PREFIX_TOTAL = 9, // total of the scan over PREFIX slice lengths
+    KMX_CTR_STITCH_MORE = 10, // STITCH queries with more further parts than the one QueryDesc::p1 names
     KMX_CTR_PREFIX_BIG = 11,  // PREFIX queries that are not 'small' (listed from the BACK of prefix_list)
     KMX_CTR_COUNT = 16
 };

@@ -156,6 +156,27 @@ def test_result_reuse_and_growth(engine, orc):
         assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), nq
 
 
+def test_pooled_results_and_results_that_outlive_their_index(engine, orc):
+    """kmx_result_free parks results in the index's pool; a later search without a result of its own takes one over
+    (buffers of another batch, possibly of another size and kind mix).  A result may be released after its index."""
+    text = synth.ranks(78, 200_000, 4)
+    idx = engine.Index(text, 4, [6, 9])
+    oidx = orc.Index(text, 4, [6, 9])
+    for rnd, nq in enumerate((300, 1, 5000, 17, 5000, 2)):
+        qranks, qoff = synth.mixed_queries(900 + rnd, text, nq, [4, 6, 9, 12, 15, 18], 4)
+        fresh = [idx.search(qranks, qoff, flags=engine.SEARCH_KEEP_MASKS if i == 1 else engine.SEARCH_DEFAULT) for i in range(3)]
+        o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=4)
+        for r in fresh:
+            ho, pos, st, _ = r.host()
+            assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos) and np.array_equal(st, o_st), (rnd, nq)
+            r.close()                                   # back to the pool
+    last = idx.search(qranks, qoff)
+    ho, pos, _, _ = last.host()
+    idx.close()                                         # the pool closes with the index ...
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    last.close()                                        # ... and a late result is simply destroyed
+
+
 def test_skewed_text_giant_buckets(engine, orc):
     """Low-entropy text: a few giant buckets (load imbalance, runs far longer than a tile, many mask words)."""
     n = 120_000

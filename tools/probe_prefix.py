@@ -15,7 +15,12 @@ text = synth.ranks(1002, n, sigma)
 idx = engine.Index(text, sigma, [k])
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
-for m, nq in ((9, 2_000_000), (8, 1_000_000), (6, 50_000), (5, 10_000), (3, 300), (13, 2_000_000), (25, 2_000_000)):
+CASES = ((9, 2_000_000), (8, 1_000_000), (6, 50_000), (5, 10_000), (3, 300), (13, 2_000_000), (25, 2_000_000),
+         (20, 2_000_000), (30, 2_000_000), (100, 2_000_000), (150, 1_000_000))
+only = [int(a) for a in sys.argv[1:]]
+for m, nq in CASES:
+    if only and m not in only:
+        continue
     q, off = synth.uniform_queries(77 + m, nq, m, sigma)
     if m > k:   # plant half so that stitches survive
         q, off = synth.mixed_queries(77 + m, text, nq, [m], sigma)
