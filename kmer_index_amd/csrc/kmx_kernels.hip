@@ -4,12 +4,14 @@
 //   k_lookup        one query per lane: rank-hash (kmer_index.hpp:56-73), planner
 //                   lookup (:512-518), bucket probe (:76-84), sub-k prefix range +
 //                   last-kmer fix-up (:115-148) -> per-query descriptor
-//  [k_validate]     one wave per STITCH query: cross-reference of the parts' buckets
-//                   (:270-298, :532-555) -> compressed_bitset mask words via ballot
+//  [k_validate]     four STITCH queries per wave: the candidates of the first part against one further
+//                   part's bucket staged in LDS (:270-298, :532-555) -> compressed_bitset mask words via
+//                   ballot + the compacted survivors
+//  [k_validate_more] queries with more parts: the survivors against every part, one part per lane
 //   k_scan_*        exclusive scan of the per-query hit counts -> hit_off
 //   k_partition     first query of every output tile
 //   k_fill          output-centric copy of bucket runs -> to_vector() lists
-//  [k_compact]      STITCH: mask-word decode, popcount prefix compaction
+//  [k_compact]      STITCH fallback without a survivor buffer: mask-word decode, popcount prefix compaction
 //  [k_merge_pass*]  PREFIX: merge of the per-key runs into one ascending list (the
 //                   std::sort of kmer_index_result.hpp:258)
 //

@@ -197,6 +197,48 @@ def test_skewed_text_giant_buckets(engine, orc):
         assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, q))
 
 
+def test_multi_part_survivors_are_dropped_from_hits_and_masks(engine, orc):
+    """Queries of several parts in a repetitive text: many candidates pass the one part k_validate filters with and
+    fail another one, so k_validate_more has to drop them — from the hit list, from the count and from the
+    compressed_bitset words (KEEP_MASKS).  Checked against the naive scan and for mask/hit consistency."""
+    rng = np.random.default_rng(5)
+    motif = rng.integers(0, 4, 61).astype(np.uint8)
+    text = np.tile(motif, 3000)
+    mut = rng.integers(0, text.size, text.size // 23)
+    text[mut] = rng.integers(0, 4, mut.size)              # mutations break most long matches but few k-mers
+    text = np.ascontiguousarray(text)
+    for ks in ([7], [6, 9, 11]):
+        idx = engine.Index(text, 4, ks, keep_host_arena=True)
+        qs = []
+        for m in (21, 28, 30, 45, 66, 100):
+            for s0 in (0, 13, 61 * 40 + 7, 61 * 1500 + 30):
+                qs.append(text[s0:s0 + m].copy())
+                qs.append(np.tile(motif, 3)[s0 % 61:s0 % 61 + m].copy())      # the unmutated repeat
+        qranks, qoff = pack(qs)
+        r = idx.search(qranks, qoff, flags=engine.SEARCH_KEEP_MASKS)
+        ho, pos, st, kd = r.host()
+        base, words_ptr, cand_cnt, cand_src = r.masks()
+        arena = idx.arena_host()
+        import ctypes as C
+        dropped = 0
+        for i, q in enumerate(qs):
+            want = orc.naive_scan(text, q)
+            got = pos[int(ho[i]):int(ho[i + 1])]
+            assert np.array_equal(got, want), (ks, i, len(q))
+            if kd[i] != engine.KIND_STITCH:
+                continue
+            nw = cand_cnt[i] // 64 + 1
+            words = np.ctypeslib.as_array(C.cast(words_ptr, C.POINTER(C.c_uint64)), shape=(int(base[i]) + nw,))[int(base[i]):]
+            bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:cand_cnt[i]].astype(bool)
+            cands = arena[int(cand_src[i]):int(cand_src[i]) + int(cand_cnt[i])]
+            assert np.array_equal(cands[bits], got), (ks, i, len(q))
+            dropped += int(cand_cnt[i]) - got.size
+        assert dropped > 1000                                # the text really makes candidates fail
+        # the count-only form runs the same validation
+        rc = idx.search(qranks, qoff, flags=engine.SEARCH_COUNT_ONLY)
+        assert np.array_equal(rc.host()[0], ho)
+
+
 def test_concurrent_host_threads_share_one_index(engine, orc):
     """kmx.h: one index may be searched from several host threads at once (search() is const in the reference,
     kmer_index.hpp:505).  Host-buffer calls serialise on the index's internal stream; device-buffer calls run on
