@@ -27,6 +27,7 @@
 #define KMX_BLOCK 256
 #define KMX_WAVE 64
 #define KMX_LOOKUP_ITEMS 4     // queries per thread in k_lookup
+#define KMX_PSORT_PAIR_CAP 512   // k_prefix_sort_small: slices up to this length are merged pairwise from registers
 #ifndef KMX_PSORT_MULTIWAY_RUNS
 #define KMX_PSORT_MULTIWAY_RUNS 4   // k_prefix_sort_small: multi-way rank pass up to this many runs, bitonic beyond
 #endif
@@ -1301,6 +1302,52 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
         }
         for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][t] = seg[t];
         wsync();
+        if (len <= KMX_PSORT_PAIR_CAP) {
+            // Up to four runs, every lane holds its (at most KMX_PSORT_PAIR_CAP / 64) positions in registers: the runs are
+            // merged pairwise in place, two rounds at most.  A position's place in the merged pair is its index in its own
+            // group plus its rank in the sibling group (no ties: positions are distinct); the searches of a lane's
+            // positions advance in lockstep, a fixed number of branch-free halving steps.
+            constexpr int C = KMX_PSORT_PAIR_CAP / KMX_WAVE;
+            uint32_t* __restrict__ b = buf[wv];
+            uint32_t e0 = bnd[wv][0], e1 = bnd[wv][1], e2 = R >= 2 ? bnd[wv][2] : len, e3 = R >= 3 ? bnd[wv][3] : len;
+            const uint32_t e4 = len;
+            for (uint32_t width = 1; width < R; width <<= 1) {
+                uint32_t longest = max(max(e1 - e0, e2 - e1), max(e3 - e2, e4 - e3));     // wave-uniform
+                uint32_t P = 1;
+                while (P <= longest) P <<= 1;
+                uint32_t x[C], own[C], s0[C], sn[C], cnt[C], tv[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const uint32_t t = lane + uint32_t(c) * KMX_WAVE;
+                    const uint32_t gi = uint32_t(t >= e1) + uint32_t(t >= e2) + uint32_t(t >= e3);     // group of t
+                    const uint32_t gs = gi == 0 ? e0 : gi == 1 ? e1 : gi == 2 ? e2 : e3;             // its start
+                    const uint32_t ps = (gi & 2) ? e2 : e0;                                           // start of the merged pair
+                    const uint32_t sb = (gi & 1) ? ps : (gi == 0 ? e1 : e3);                          // sibling: start ...
+                    const uint32_t se = (gi & 1) ? gs : (gi == 0 ? e2 : e4);                          // ... and end
+                    x[c] = b[min(t, len - 1)];
+                    own[c] = ps + (t - gs);
+                    s0[c] = sb;
+                    sn[c] = se - sb;
+                    cnt[c] = 0;
+                }
+                for (uint32_t st = P >> 1; st; st >>= 1) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) tv[c] = b[min(s0[c] + cnt[c] + st - 1, len - 1)];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) cnt[c] += (cnt[c] + st - 1 < sn[c] && tv[c] < x[c]) ? st : 0u;
+                }
+                wsync();                                               // every read of this round is done
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (lane + uint32_t(c) * KMX_WAVE < len) b[own[c] + cnt[c]] = x[c];
+                wsync();
+                // the pairs are the groups of the next round
+                e1 = e2; e2 = e4; e3 = e4;
+            }
+            for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = b[t];
+            wsync();                                                   // buf/bnd are reused by the next query
+            continue;
+        }
         for (uint32_t t = lane; t < len; t += KMX_WAVE) {
             const uint32_t x = buf[wv][t];
             uint32_t pos = 0;
