@@ -514,7 +514,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     auto up32 = [](uint64_t v) { return (v + 31) & ~uint64_t(31); };
     uint64_t max_keys = 0;
     for (uint32_t i = 0; i < n_ks; ++i) {
-        const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i]));
+        const uint64_t nk = kmx::key_space(sigma, ks[i]);
         if (!o.host_flatten && nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
     }
     // per device-built element, filled by phase 1
@@ -536,7 +536,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         // phase 1: histogram, offsets (= the dense table), sizes
         for (uint32_t i = 0; i < n_ks; ++i) {
             if (!on_device[i]) continue;
-            const uint64_t nk = kmx::fast_pow(sigma, uint8_t(ks[i])), npos = n - ks[i] + 1;
+            const uint64_t nk = kmx::key_space(sigma, ks[i]), npos = n - ks[i] + 1;
             e = hipMalloc(reinterpret_cast<void**>(&dev[i].d_offs), (nk + 1) * 4 + 64);
             if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("offs: ") + hipGetErrorString(e)); }
             kmx::launch_build_phase1(nullptr, d_text, n, ks[i], sigma, nk, d_hist, d_scr, d_bsum, dev[i].d_offs, d_cursor, d_info, d_total);
@@ -1176,7 +1176,7 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
     uint32_t kmax = 0;
     for (const FileElem& fe : fes) {
         const bool dense = fe.table_kind == KMX_TABLE_DENSE, open = fe.table_kind == KMX_TABLE_OPEN;
-        if (!kmx::k_is_valid(fh.sigma, fe.k) || fe.npos != fh.n - fe.k + 1 || fe.n_keys != kmx::fast_pow(fh.sigma, uint8_t(fe.k)) || !(dense || open) ||
+        if (!kmx::k_is_valid(fh.sigma, fe.k) || fe.npos != fh.n - fe.k + 1 || fe.n_keys != kmx::key_space(fh.sigma, fe.k) || !(dense || open) ||
             (dense && (fe.n_offs != fe.n_keys + 1 || fe.n_slots || fe.n_ukeys)) ||
             (open && (fe.n_offs != fe.n_ukeys + 1 || fe.log2cap > 40 || fe.n_slots != (uint64_t(1) << fe.log2cap) || fe.n_ukeys > fe.npos)) ||
             fe.region < fe.npos || fe.region >= 0xFFFFFFFFull || (fe.n_aoffs != 0 && !(dense && fe.n_aoffs == fe.n_keys + 1 && fe.region > fe.npos)))

@@ -21,6 +21,13 @@ uint64_t fast_pow(uint64_t base, uint8_t exp)
     return result;
 }
 
+uint64_t key_space(uint32_t sigma, uint32_t k)
+{
+    uint64_t v = 1;
+    for (uint32_t i = 0; i < k; ++i) v *= sigma;
+    return v;
+}
+
 bool k_is_valid(uint32_t sigma, uint32_t k)
 {
     if (sigma < 2 || sigma > 256 || k == 0) return false;
@@ -147,7 +154,7 @@ void build_slots(ElemImage& im)
 uint32_t resolve_table_kind(uint32_t sigma, uint32_t k, uint64_t n, uint32_t requested)
 {
     if (requested != KMX_TABLE_AUTO) return requested;
-    const uint64_t n_keys = fast_pow(sigma, uint8_t(k)), npos = n - k + 1, HIST_MAX = uint64_t(1) << 30;
+    const uint64_t n_keys = key_space(sigma, k), npos = n - k + 1, HIST_MAX = uint64_t(1) << 30;
     return (n_keys <= 4 * npos && n_keys <= HIST_MAX) ? KMX_TABLE_DENSE : KMX_TABLE_OPEN;
 }
 
@@ -190,7 +197,7 @@ bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t 
     im = ElemImage();
     im.k = k;
     im.npos = n - k + 1;
-    im.n_keys = fast_pow(sigma, uint8_t(k));
+    im.n_keys = key_space(sigma, k);
     const uint64_t HIST_MAX = uint64_t(1) << 30;
     if (table_kind == KMX_TABLE_AUTO)
         table_kind = (im.n_keys <= 4 * im.npos && im.n_keys <= HIST_MAX) ? KMX_TABLE_DENSE : KMX_TABLE_OPEN;
@@ -200,7 +207,7 @@ bool flatten_element(const uint8_t* ranks, uint64_t n, uint32_t sigma, uint32_t 
     }
     im.table_kind = table_kind;
     im.positions.resize(im.npos);
-    const uint64_t top = fast_pow(sigma, uint8_t(k - 1));
+    const uint64_t top = key_space(sigma, k - 1);
 
     auto first_hash = [&]() {
         uint64_t h = 0;

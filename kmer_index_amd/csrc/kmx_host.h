@@ -9,6 +9,9 @@
 namespace kmx {
 
 uint64_t fast_pow(uint64_t base, uint8_t exp);
+// sigma^k exactly, for a valid k (k_is_valid: the product fits 64 bits).  NOT fast_pow: the reference's fast_pow
+// returns 0 from exp == 63 on (fast_pow.hpp:19), which is what (sigma, k) = (2, 63) would ask it for.
+uint64_t key_space(uint32_t sigma, uint32_t k);
 
 // kmer_index::choose_search_scheme (kmer_index.hpp:407-476).
 struct Plan {

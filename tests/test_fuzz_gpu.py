@@ -1,5 +1,7 @@
 """Randomised differential test: engine (through the C-ABI) vs the CPU oracle over random index shapes,
 layouts and query mixes.  Seeds are fixed; a failure message carries the case so it can be replayed."""
+import os
+
 import numpy as np
 import pytest
 
@@ -77,7 +79,8 @@ def _make_queries(rng, sigma, ks, text, count=260):
     return qs
 
 
-@pytest.mark.parametrize("seed", range(96))
+# KMX_FUZZ_SEEDS / KMX_FUZZ_FIRST widen or move the seed window for a longer soak (default: the 96 committed seeds)
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KMX_FUZZ_FIRST", 0)), int(os.environ.get("KMX_FUZZ_FIRST", 0)) + int(os.environ.get("KMX_FUZZ_SEEDS", 96))))
 def test_random_index_and_queries(engine, orc, seed):
     rng = np.random.default_rng(1000 + seed)
     sigma, ks, text, style = _make_case(rng)

@@ -156,6 +156,26 @@ def test_result_reuse_and_growth(engine, orc):
         assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), nq
 
 
+@pytest.mark.parametrize("sigma,k", [(2, 63), (3, 40), (4, 31), (5, 27), (20, 14), (27, 13)])
+def test_largest_valid_k_of_an_alphabet(engine, orc, sigma, k):
+    """k at the limit of static_assert(k < 64 / log2(sigma)) (kmer_index.hpp:42-43): hashes use (nearly) all 64 bits.
+    (2, 63) is the one pair whose key space the reference's fast_pow cannot express — fast_pow(2, 63) == 0
+    (fast_pow.hpp:19) — found by the fuzz soak, seed 704."""
+    rng = np.random.default_rng(sigma * 100 + k)
+    text = (rng.integers(0, sigma, 9000) * (rng.integers(0, 3, 9000) == 0)).astype(np.uint8)    # low entropy: repeats exist
+    idx = engine.Index(text, sigma, [k], table=engine.TABLE_OPEN)
+    qs = [text[s0:s0 + m].copy() for m in (k, k, 2 * k, 2 * k + 3, k + 1, 3 * k) for s0 in (0, 17, 4000, 9000 - 3 * k)]
+    qs += [rng.integers(0, sigma, k).astype(np.uint8), np.zeros(k, np.uint8), np.zeros(2 * k + 1, np.uint8)]
+    qranks, qoff = pack(qs)
+    ho, pos, st, _ = idx.search(qranks, qoff).host()
+    o_off, o_pos, o_st, _ = orc.Index(text, sigma, [k]).search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=2)
+    assert np.array_equal(st, o_st.astype(np.uint8)) and np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    assert int((st == 0).sum()) >= 15                         # (a rest of 1..3 letters is the fan-out error, :119-122)
+    for i, q in enumerate(qs):
+        if st[i] == 0:
+            assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, q))
+
+
 def test_pooled_results_and_results_that_outlive_their_index(engine, orc):
     """kmx_result_free parks results in the index's pool; a later search without a result of its own takes one over
     (buffers of another batch, possibly of another size and kind mix).  A result may be released after its index."""
