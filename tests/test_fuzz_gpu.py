@@ -107,7 +107,7 @@ def test_random_index_and_queries(engine, orc, seed):
     idx.close()
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KMX_FUZZ_LARGE_SEEDS", 12))))
 def test_random_large_batches(engine, orc, seed):
     """The same, with batches of ~20 K queries (many blocks, many tiles, long work lists, ragged tails)."""
     rng = np.random.default_rng(5000 + seed)
@@ -128,4 +128,58 @@ def test_random_large_batches(engine, orc, seed):
         assert np.array_equal(st, o_st.astype(np.uint8)), case
         assert np.array_equal(ho, o_off), case
         assert np.array_equal(pos, o_pos), case
+    idx.close()
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("KMX_FUZZ_LONG_SEEDS", 24))))
+def test_random_long_queries(engine, orc, seed):
+    """Queries of many parts (up to ~60 k-parts or multi-k summands) over repetitive texts: most candidates pass
+    the part k_validate filters with, so k_validate_more sees long survivor lists and drops many of them; the walk
+    over _optimal_nk_sum runs deep.  Ground truth: the naive scan (the reference itself is wrong from three
+    parts on), plus the oracle in INTENDED mode for the statuses."""
+    rng = np.random.default_rng(9000 + seed)
+    sigma = int(rng.choice([2, 3, 4, 5, 20]))
+    kcap = {2: 14, 3: 10, 4: 9, 5: 8, 20: 4}[sigma]
+    multi = rng.random() < 0.5
+    if multi:
+        ks = sorted(set(int(x) for x in rng.integers(max(2, kcap - 4), kcap + 6, 3)))      # high ks -> multi-k schemes
+        ks = [k for k in ks if k < 64 / np.log2(sigma)]
+    else:
+        ks = [int(rng.integers(2, kcap + 1))]
+    kmax = max(ks)
+    n = int(rng.integers(5_000, 60_000))
+    period = int(rng.integers(3, 200))
+    text = np.resize(synth.ranks(int(rng.integers(1, 1 << 30)), period, sigma), n).astype(np.uint8)
+    mut = rng.integers(0, n, max(1, n // int(rng.integers(20, 400))))
+    text[mut] = rng.integers(0, sigma, mut.size)
+    text = np.ascontiguousarray(text)
+    qs = []
+    while len(qs) < 160:
+        m = int(rng.integers(kmax + 1, min(60 * min(ks), 600, n // 2)))
+        if not all(_fanout_ok(sigma, k, m) for k in ks):
+            continue
+        s0 = int(rng.integers(0, n - m + 1))
+        q = text[s0:s0 + m].copy()
+        r = rng.random()
+        if r < 0.3:                                           # one letter changed somewhere: kills the match late or early
+            j = int(rng.integers(0, m))
+            q[j] = (int(q[j]) + 1) % sigma
+        elif r < 0.4:
+            q = np.resize(text[:period], m).astype(np.uint8)  # the unmutated repeat
+        qs.append(q)
+    qranks, qoff = pack(qs)
+    flags = engine.SEARCH_KEEP_MASKS if seed % 2 else engine.SEARCH_DEFAULT
+    kw = dict(table=[engine.TABLE_AUTO, engine.TABLE_OPEN][seed % 2], aligned_copy=bool(seed % 3))
+    case = f"seed={seed} sigma={sigma} ks={ks} n={n} period={period} {kw}"
+    idx = engine.Index(text, sigma, ks, **kw)
+    res = idx.search(qranks, qoff, flags=flags)
+    ho, pos, st, kd = res.host()
+    o_off, o_pos, o_st, _ = orc.Index(text, sigma, ks).search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=8)
+    assert np.array_equal(st, o_st.astype(np.uint8)), case
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), case
+    for i in range(0, len(qs), 7):
+        if st[i] == 0:
+            assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, qs[i])), (case, i)
+    rc = idx.search(qranks, qoff, flags=engine.SEARCH_COUNT_ONLY)
+    assert np.array_equal(rc.host()[0], ho), case
     idx.close()
