@@ -15,6 +15,8 @@
 #include <cstdint>
 #include <iterator>
 #include <memory>
+#include <stdexcept>
+#include <string>
 #include <vector>
 
 #include "compressed_bitset.hpp"
@@ -58,7 +60,17 @@ namespace kmer::detail
 
         const_iterator begin() const { return _hits; }
         const_iterator end() const { return _hits + _n_hits; }
-        position_t at(std::size_t i) const { return to_vector().at(i); }
+        // the i-th valid position (the intended `at` of ~kmer_index_result.hpp:223-241); std::out_of_range past the end
+        position_t at(std::size_t i) const
+        {
+            if (i >= _n_hits) throw std::out_of_range("kmer_index_result::at: index " + std::to_string(i) + " out of range");
+            return _hits[i];
+        }
+        position_t operator[](std::size_t i) const { return _hits[i]; }
+
+        // should_use / should_not_use (kmer_index_result.hpp:228-236): validity of candidate i
+        bool should_use(std::size_t i) const { return is_valid(i); }
+        bool should_not_use(std::size_t i) const { return !is_valid(i); }
 
         // the zero-copy view of the reference: candidates + validity mask
         bool bypasses_bitmask() const { return _bypass_bitmask; }

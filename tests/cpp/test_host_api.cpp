@@ -81,6 +81,12 @@ void run_test(std::size_t text_size, std::uint64_t seed)
         auto truth = naive(text, queries[i]);
         CHECK(batch[i].to_vector() == truth);
         CHECK(batch[i].size() == truth.size());
+        if (!truth.empty()) CHECK(batch[i].at(truth.size() - 1) == truth.back() && batch[i][0] == truth.front());
+        {
+            bool threw = false;
+            try { (void)batch[i].at(truth.size()); } catch (const std::out_of_range&) { threw = true; }
+            CHECK(threw);
+        }
         std::vector<std::uint32_t> via_iter(batch[i].begin(), batch[i].end());
         CHECK(via_iter == truth);
         if (!batch[i].bypasses_bitmask())
@@ -88,7 +94,7 @@ void run_test(std::size_t text_size, std::uint64_t seed)
             // zero-copy view: candidates filtered by the mask == to_vector()
             std::vector<std::uint32_t> filtered;
             for (std::size_t c = 0; c < batch[i].n_candidates(); ++c)
-                if (batch[i].is_valid(c)) filtered.push_back(batch[i].candidates()[c]);
+                if (batch[i].should_use(c) && !batch[i].should_not_use(c)) filtered.push_back(batch[i].candidates()[c]);
             CHECK(filtered == truth);
             CHECK(batch[i].bitmask().count_bits_equal_to(true) == truth.size());
         }
