@@ -189,9 +189,21 @@ def main():
             t1 = time.perf_counter()
             oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=T, keep_hits=False)
             dt = time.perf_counter() - t1
+            n1 = min(ns, 1_000_000)                               # the same restatement on one thread ("also T=1")
+            t1 = time.perf_counter()
+            oidx.search_batch(qr_host[:n1 * m], qoff_host[:n1 + 1], n_threads=1, keep_hits=False)
+            dt1 = time.perf_counter() - t1
+            cpu_model = "unknown CPU"
+            try:
+                with open("/proc/cpuinfo") as f:
+                    cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+            except Exception:
+                pass
             cpu_baseline = {"value": round(ns / dt / 1e6, 4), "unit": "M queries/s", "cores": T, "kind": "port",
                             "sample": f"first {ns} of the {nq} queries, same 1e8-bp text, search(q).to_vector() per query "
-                                      f"on the oracle's thread pool ({T} threads, std::unordered_map buckets), {dt:.1f}s wall"}
+                                      f"on the oracle's thread pool ({T} threads of {usable} usable, {cpu_model}; "
+                                      f"std::unordered_map buckets), {dt:.1f}s wall",
+                            "single_thread_value": round(n1 / dt1 / 1e6, 4), "single_thread_sample": f"first {n1} queries, {dt1:.1f}s"}
             o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
             oidx.close()

@@ -6,7 +6,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libkmx.so")
-SOURCES = ["kmx_kernels.hip", "kmx_capi.hip", "kmx_host.cpp"]
+SOURCES = ["kmx_kernels.hip", "kmx_capi.hip", "kmx_build_sort.hip", "kmx_host.cpp"]
 HEADERS = ["kmx_types.h", "kmx_host.h", "kmx_kernels.h", os.path.join("..", "..", "include", "kmx.h")]
 
 

@@ -305,6 +305,8 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     for (auto& im : images) {   // device-built dense tables
         if (im.d_offs_prebuilt) ix->allocs.push_back(const_cast<uint32_t*>(im.d_offs_prebuilt));
         if (im.d_atab_prebuilt) ix->allocs.push_back(const_cast<uint32_t*>(im.d_atab_prebuilt));
+        if (im.d_ukeys_prebuilt) ix->allocs.push_back(const_cast<uint64_t*>(im.d_ukeys_prebuilt));
+        if (im.d_slots_prebuilt) ix->allocs.push_back(const_cast<KmxSlot*>(im.d_slots_prebuilt));
     }
 
     KmxIndexDev h{};
@@ -351,7 +353,8 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     for (uint32_t i = 0; i < n_ks; ++i) {
         auto& im = images[i];
         KmxElemDev& el = h.elems[i];
-        el.k = im.k; el.table_kind = im.table_kind; el.log2cap = im.log2cap; el.n_ukeys = uint32_t(im.ukeys.size());
+        el.k = im.k; el.table_kind = im.table_kind; el.log2cap = im.log2cap;
+        el.n_ukeys = uint32_t(im.d_ukeys_prebuilt ? im.n_ukeys_prebuilt : im.ukeys.size());
         if (im.region > im.npos) base = (base + 31) & ~uint64_t(31);
         el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos; el.region = im.region; el.atab = nullptr;
         ix->table_kinds.push_back(im.table_kind);
@@ -371,7 +374,12 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
                 ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.begin() + im.region);
             }
         }
-        if (im.d_offs_prebuilt) {
+        if (im.d_ukeys_prebuilt) {                              // open table built on the device
+            const uint64_t nu = im.n_ukeys_prebuilt, cap = uint64_t(1) << im.log2cap;
+            el.offs = im.d_offs_prebuilt; el.ukeys = im.d_ukeys_prebuilt; el.slots = im.d_slots_prebuilt;
+            ix->device_bytes += (nu + 1) * 4 + nu * 8 + cap * sizeof(KmxSlot);
+            ix->elem_sizes.back() = {size_t(nu + 1), size_t(cap), size_t(nu), size_t(0)};
+        } else if (im.d_offs_prebuilt) {
             el.offs = im.d_offs_prebuilt;                       // (owned by ix->allocs since the top of this function)
             ix->device_bytes += (im.n_keys + 1) * 4;
             ix->elem_sizes.back().n_offs = im.n_keys + 1;
@@ -382,7 +390,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         } else if (im.table_kind == KMX_TABLE_DENSE && !im.atab.empty()) {
             if ((st = upload(ix, im.atab.data(), im.atab.size(), &el.atab)) != KMX_OK) return bail(st);
         }
-        if (im.table_kind == KMX_TABLE_OPEN) {
+        if (im.table_kind == KMX_TABLE_OPEN && !im.d_ukeys_prebuilt) {
             if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
             if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
         }
@@ -513,9 +521,13 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     const uint64_t DEVICE_BUILD_MAX_KEYS = uint64_t(1) << 26;
     auto up32 = [](uint64_t v) { return (v + 31) & ~uint64_t(31); };
     uint64_t max_keys = 0;
+    std::vector<char> sparse(n_ks, 0);   // key space beyond the histogram: sorted (hash, position) pairs, open table (kmx_build_sort.hip)
+    bool any_sparse = false;
     for (uint32_t i = 0; i < n_ks; ++i) {
         const uint64_t nk = kmx::key_space(sigma, ks[i]);
-        if (!o.host_flatten && nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
+        if (o.host_flatten) continue;
+        if (nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
+        else if (kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind) == KMX_TABLE_OPEN) { sparse[i] = 1; any_sparse = true; }
     }
     // per device-built element, filled by phase 1
     struct DevElem { uint32_t* d_offs = nullptr; uint32_t* d_aoffs = nullptr; uint32_t* d_atab = nullptr; uint32_t max_bucket = 0; uint64_t a0 = 0; };
@@ -523,6 +535,11 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     auto free_dev = [&] { for (auto& de : dev) { if (de.d_offs) (void)hipFree(de.d_offs); if (de.d_aoffs) (void)hipFree(de.d_aoffs); if (de.d_atab) (void)hipFree(de.d_atab); de = DevElem(); } };
     uint8_t* d_text = nullptr; uint32_t* d_hist = nullptr; uint64_t* d_scr = nullptr; uint64_t* d_bsum = nullptr; uint32_t* d_cursor = nullptr;
     unsigned int* d_info = nullptr; unsigned long long* d_total = nullptr;
+    if (any_sparse && !max_keys) {
+        hipError_t e = scratch.get(&d_text, n);
+        if (e == hipSuccess) e = hipMemcpy(d_text, ranks, n, hipMemcpyHostToDevice);
+        if (e != hipSuccess) return fail(KMX_ERR_OUT_OF_MEMORY, std::string("device build scratch: ") + hipGetErrorString(e));
+    }
     if (max_keys) {
         hipError_t e = scratch.get(&d_text, n);
         if (e == hipSuccess) e = scratch.get(&d_hist, max_keys);
@@ -580,13 +597,20 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
                 for (;;) {
                     uint32_t i = next.fetch_add(1);
                     if (i >= n_ks) return;
-                    if (!on_device[i]) oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i], aligned_copy);
+                    if (!on_device[i] && !sparse[i]) oks[i] = kmx::flatten_element(ranks, n, sigma, ks[i], o.table_kind, images[i], errs[i], aligned_copy);
                 }
             });
         for (auto& t : threads) t.join();
     }
     for (uint32_t i = 0; i < n_ks; ++i)
         if (!oks[i]) { free_dev(); return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: " + errs[i]); }
+
+    for (uint32_t i = 0; i < n_ks; ++i)
+        if (sparse[i]) {
+            kmx::ElemImage& im = images[i];
+            im.k = ks[i]; im.n_keys = kmx::key_space(sigma, ks[i]); im.npos = n - ks[i] + 1; im.region = im.npos;
+            im.table_kind = KMX_TABLE_OPEN; im.positions_on_device = true;
+        }
 
     // 3. every region is known now: allocate the arena, then phase 2 of the device-built elements
     uint64_t arena_elems = 0;
@@ -601,6 +625,26 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
         if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); }
     }
+    auto free_sparse = [&] {
+        for (auto& im : images) {
+            if (im.d_ukeys_prebuilt) { (void)hipFree(const_cast<uint64_t*>(im.d_ukeys_prebuilt)); (void)hipFree(const_cast<uint32_t*>(im.d_offs_prebuilt));
+                                       (void)hipFree(const_cast<KmxSlot*>(im.d_slots_prebuilt)); im.d_ukeys_prebuilt = nullptr; im.d_offs_prebuilt = nullptr; im.d_slots_prebuilt = nullptr; }
+        }
+    };
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        if (!sparse[i]) continue;
+        kmx::ElemImage& im = images[i];
+        uint32_t key_bits = 1;
+        while (key_bits < 64 && (im.n_keys - 1) >> key_bits) ++key_bits;
+        kmx::SparseTables t;
+        hipError_t e = kmx::build_sparse_element(nullptr, d_text, n, ks[i], sigma, key_bits, static_cast<uint32_t*>(arena) + bases[i], &t);
+        if (e != hipSuccess) {
+            free_dev(); free_sparse(); (void)hipFree(arena);
+            return fail(e == hipErrorOutOfMemory ? KMX_ERR_OUT_OF_MEMORY : KMX_ERR_HIP, std::string("device build (sorted pairs): ") + hipGetErrorString(e));
+        }
+        im.d_ukeys_prebuilt = t.d_ukeys; im.d_offs_prebuilt = t.d_offs; im.d_slots_prebuilt = t.d_slots;
+        im.n_ukeys_prebuilt = t.n_ukeys; im.log2cap = t.log2cap;
+    }
     for (uint32_t i = 0; i < n_ks; ++i) {
         if (!on_device[i]) continue;
         kmx::ElemImage& im = images[i];
@@ -608,7 +652,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         kmx::launch_build_phase2(nullptr, d_text, n, ks[i], sigma, im.n_keys, dev[i].d_offs, d_hist, d_scr, d_bsum, d_cursor, d_info, d_total,
                                  d_region, dev[i].d_aoffs, uint32_t(dev[i].a0), dev[i].max_bucket > KMX_PSORT_CAP, dev[i].d_atab, uint32_t(im.region));
         hipError_t e = hipDeviceSynchronize();
-        if (e != hipSuccess) { free_dev(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { free_dev(); free_sparse(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
         if (im.table_kind == KMX_TABLE_DENSE) {
             im.d_offs_prebuilt = dev[i].d_offs;                      // the dense table itself
             im.d_atab_prebuilt = dev[i].d_atab;
@@ -622,7 +666,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
                 astart.resize(im.n_keys);
                 e = hipMemcpy(astart.data(), dev[i].d_aoffs, im.n_keys * 4, hipMemcpyDeviceToHost);
             }
-            if (e != hipSuccess) { free_dev(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("offs download: ") + hipGetErrorString(e)); }
+            if (e != hipSuccess) { free_dev(); free_sparse(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("offs download: ") + hipGetErrorString(e)); }
             im.offs.push_back(0);
             for (uint64_t j = 0; j < im.n_keys; ++j)
                 if (start[j + 1] != start[j]) {

@@ -43,6 +43,10 @@ struct ElemImage {
     bool positions_on_device = false;
     const uint32_t* d_offs_prebuilt = nullptr;
     const uint32_t* d_atab_prebuilt = nullptr;
+    // open table built on the device (kmx_build_sort.hip): d_offs_prebuilt holds n_ukeys_prebuilt + 1 boundaries
+    const uint64_t* d_ukeys_prebuilt = nullptr;
+    const KmxSlot* d_slots_prebuilt = nullptr;
+    uint64_t n_ukeys_prebuilt = 0;
 };
 
 // Builds the image of one element — the work of kmer_index_element::create

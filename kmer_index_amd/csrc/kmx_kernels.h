@@ -28,6 +28,19 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);
+
+// kmx_build_sort.hip — device construction of an element with a key space beyond the histogram path:
+// positions (grouped by hash, ascending inside a group) into d_positions[n - k + 1], tables into new allocations
+// the caller owns.  key_bits = bits needed for sigma^k - 1 (the radix sort skips the rest).
+struct SparseTables {
+    uint64_t* d_ukeys = nullptr;   // n_ukeys distinct hashes, ascending
+    uint32_t* d_offs = nullptr;    // n_ukeys + 1 group boundaries
+    KmxSlot* d_slots = nullptr;    // 1 << log2cap open-addressing slots
+    uint64_t n_ukeys = 0;
+    uint32_t log2cap = 0;
+};
+hipError_t build_sparse_element(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint32_t key_bits,
+                                uint32_t* d_positions, SparseTables* out);
 void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
                  unsigned long long* total_out);
 // k_fill build variants: e = output slots per thread (tile = 256 * e), nt = non-temporal stores

@@ -397,6 +397,37 @@ def test_prefix_sort_all_size_classes(engine, orc):
     assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_merge_pass"]["launches"]
 
 
+@pytest.mark.parametrize("sigma,ks", [(4, [16]), (4, [14, 20, 31]), (2, [40, 63]), (20, [7, 12]), (5, [12, 4])])
+def test_sorted_pairs_device_build_equals_host_flatten(engine, orc, sigma, ks, tmp_path):
+    """Elements whose key space is beyond the histogram path (sigma^k > 2^26) are built on the device from sorted
+    (hash, position) pairs (kmx_build_sort.hip): same arena as the host flatten, same answers — exact, stitched
+    and prefix queries, which read the slots, the candidates and the sorted key / offset arrays — and the image
+    written from the device-built tables loads back."""
+    rng = np.random.default_rng(sigma * 7 + ks[0])
+    text = (rng.integers(0, sigma, 300_000) * (rng.integers(0, 4, 300_000) != 0)).astype(np.uint8)   # biased: repeats exist
+    text[100_000:100_400] = text[:400]
+    dev = engine.Index(text, sigma, ks, keep_host_arena=True)
+    host = engine.Index(text, sigma, ks, keep_host_arena=True, host_flatten=True)
+    assert np.array_equal(dev.arena_host(), host.arena_host())
+    assert dev.info()["tables"] == host.info()["tables"]
+    kmax = max(ks)
+    lens = sorted({max(1, min(ks) - 2), min(ks), kmax - 1, kmax, kmax + 3, 2 * kmax, 3 * kmax + 1})
+    qranks, qoff = make_queries(text, sigma, lens, 24, seed=3)
+    a = dev.search(qranks, qoff).host()
+    b = host.search(qranks, qoff).host()
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y)
+    o_off, o_pos, o_st, _ = orc.Index(text, sigma, ks).search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=4)
+    assert np.array_equal(a[0], o_off) and np.array_equal(a[1], o_pos) and np.array_equal(a[2], o_st.astype(np.uint8))
+    assert int(o_off[-1]) > 30
+    path = str(tmp_path / "sparse.img")
+    dev.save(path)
+    again = engine.Index.load(path)
+    c = again.search(qranks, qoff).host()
+    for x, y in zip(a, c):
+        assert np.array_equal(x, y)
+
+
 @pytest.mark.parametrize("table", ["open", "dense"])
 def test_device_built_index_equals_host_flatten(engine, orc, table):
     """Index construction on the device (k_build_*, k_bucket_sort_*) yields the same arena as the host flatten
