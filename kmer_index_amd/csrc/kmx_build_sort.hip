@@ -90,27 +90,45 @@ inline unsigned int blocks(uint64_t n) { return (unsigned int)((n + kBlock - 1) 
 
 } // namespace
 
+// (hash, position) pairs of every k-mer, stably sorted by hash: positions -> d_positions, sorted hashes -> keys_b
+static hipError_t sort_pairs(hipStream_t s, const uint8_t* d_text, uint64_t npos, uint32_t k, uint32_t sigma, uint32_t key_bits,
+                             uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals, uint32_t* d_positions)
+{
+    hipLaunchKernelGGL(k_sparse_pairs, dim3(blocks(npos)), dim3(kBlock), 0, s, d_text, npos, k, sigma, keys_a, vals);
+    Temp sort_tmp;
+    size_t tmp_bytes = 0;
+    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals, d_positions, size_t(npos), 0u, key_bits, s);
+    if (e == hipSuccess) e = sort_tmp.alloc(tmp_bytes);
+    if (e == hipSuccess) e = rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys_a, keys_b, vals, d_positions, size_t(npos), 0u, key_bits, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                      // sort_tmp is released on return
+    return e;
+}
+
+hipError_t sort_kmer_positions(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint32_t key_bits,
+                               uint32_t* d_positions)
+{
+    const uint64_t npos = n - k + 1;
+    Temp keys_a, keys_b, vals;
+    hipError_t e = keys_a.alloc(npos * 8);
+    if (e == hipSuccess) e = keys_b.alloc(npos * 8);
+    if (e == hipSuccess) e = vals.alloc(npos * 4);
+    if (e != hipSuccess) return e;
+    return sort_pairs(s, d_text, npos, k, sigma, key_bits, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals.as<uint32_t>(), d_positions);
+}
+
 hipError_t build_sparse_element(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint32_t key_bits,
                                 uint32_t* d_positions, SparseTables* out)
 {
     static_assert(sizeof(KmxSlot) == 16, "slot layout: {u64 key, u32 off, u32 cnt}");
     *out = SparseTables{};
     const uint64_t npos = n - k + 1;
-    Temp keys_a, keys_b, vals, sort_tmp, bsum;
+    Temp keys_a, keys_b, vals, bsum;
     hipError_t e = keys_a.alloc((npos + 1) * 8);
     if (e == hipSuccess) e = keys_b.alloc((npos + 1) * 8);
     if (e == hipSuccess) e = vals.alloc(npos * 4);
     if (e == hipSuccess) e = bsum.alloc((scan_blocks(npos) + 1) * 8);                // block sums + the scan's total
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sparse_pairs, dim3(blocks(npos)), dim3(kBlock), 0, s, d_text, npos, k, sigma, keys_a.as<uint64_t>(), vals.as<uint32_t>());
-
-    size_t tmp_bytes = 0;
-    e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals.as<uint32_t>(), d_positions,
-                                  size_t(npos), 0u, key_bits, s);
-    if (e == hipSuccess) e = sort_tmp.alloc(tmp_bytes);
-    if (e == hipSuccess)
-        e = rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals.as<uint32_t>(), d_positions,
-                                      size_t(npos), 0u, key_bits, s);
+    e = sort_pairs(s, d_text, npos, k, sigma, key_bits, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), vals.as<uint32_t>(), d_positions);
     if (e != hipSuccess) return e;
 
     // heads of the runs -> index of every distinct key (vals and keys_a are free again)

@@ -563,13 +563,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
             if (e == hipSuccess) e = hipMemcpy(totals, d_total, sizeof totals, hipMemcpyDeviceToHost);
             if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
             kmx::ElemImage& im = images[i];
-            if (info[0] > KMX_PSORT_BLOCK_CAP) {
-                // a bucket too large for the LDS sorts (heavily repetitive text): this element goes to the host flatten
-                (void)hipFree(dev[i].d_offs);
-                dev[i] = DevElem();
-                on_device[i] = 0;
-                continue;
-            }
+            // (a bucket too large for the LDS sorts — heavily repetitive text: phase 2 radix-sorts (hash, position) pairs instead)
             dev[i].max_bucket = info[0];
             im.k = ks[i]; im.n_keys = nk; im.npos = npos; im.positions_on_device = true;
             im.table_kind = kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind);
@@ -649,9 +643,18 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         if (!on_device[i]) continue;
         kmx::ElemImage& im = images[i];
         uint32_t* d_region = static_cast<uint32_t*>(arena) + bases[i];
-        kmx::launch_build_phase2(nullptr, d_text, n, ks[i], sigma, im.n_keys, dev[i].d_offs, d_hist, d_scr, d_bsum, d_cursor, d_info, d_total,
-                                 d_region, dev[i].d_aoffs, uint32_t(dev[i].a0), dev[i].max_bucket > KMX_PSORT_CAP, dev[i].d_atab, uint32_t(im.region));
-        hipError_t e = hipDeviceSynchronize();
+        int sort_mode = dev[i].max_bucket > KMX_PSORT_BLOCK_CAP ? 2 : dev[i].max_bucket > KMX_PSORT_CAP ? 1 : 0;
+        hipError_t e = hipSuccess;
+        if (sort_mode == 2) {
+            uint32_t key_bits = 1;
+            while (key_bits < 64 && (im.n_keys - 1) >> key_bits) ++key_bits;
+            e = kmx::sort_kmer_positions(nullptr, d_text, n, ks[i], sigma, key_bits, d_region);
+        }
+        if (e == hipSuccess) {
+            kmx::launch_build_phase2(nullptr, d_text, n, ks[i], sigma, im.n_keys, dev[i].d_offs, d_hist, d_scr, d_bsum, d_cursor, d_info, d_total,
+                                     d_region, dev[i].d_aoffs, uint32_t(dev[i].a0), sort_mode, dev[i].d_atab, uint32_t(im.region));
+            e = hipDeviceSynchronize();
+        }
         if (e != hipSuccess) { free_dev(); free_sparse(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
         if (im.table_kind == KMX_TABLE_DENSE) {
             im.d_offs_prebuilt = dev[i].d_offs;                      // the dense table itself

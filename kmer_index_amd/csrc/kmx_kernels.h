@@ -39,6 +39,10 @@ struct SparseTables {
     uint64_t n_ukeys = 0;
     uint32_t log2cap = 0;
 };
+// only the positions, grouped by hash and ascending inside a group (for an element whose tables come from the
+// histogram but whose buckets are too long for the LDS sorts)
+hipError_t sort_kmer_positions(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint32_t key_bits,
+                               uint32_t* d_positions);
 hipError_t build_sparse_element(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint32_t key_bits,
                                 uint32_t* d_positions, SparseTables* out);
 void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
@@ -66,7 +70,7 @@ void launch_build_phase1(hipStream_t s, const uint8_t* d_text, uint64_t n, uint3
 void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
                          const uint32_t* d_offs, uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_cursor,
                          unsigned int* d_info, unsigned long long* d_total, uint32_t* d_region, uint32_t* d_aoffs, uint32_t a0,
-                         bool block_sort, uint32_t* d_atab, uint32_t region_end);
+                         int sort_mode, uint32_t* d_atab, uint32_t region_end);
 void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_keys, uint32_t* d_positions);
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
                               const uint64_t* hit_off, uint32_t* out);

@@ -1733,15 +1733,19 @@ void launch_build_phase1(hipStream_t s, const uint8_t* d_text, uint64_t n, uint3
 void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
                          const uint32_t* d_offs, uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_cursor,
                          unsigned int* d_info, unsigned long long* d_total, uint32_t* d_region, uint32_t* d_aoffs, uint32_t a0,
-                         bool block_sort, uint32_t* d_atab, uint32_t region_end)
+                         int sort_mode, uint32_t* d_atab, uint32_t region_end)
 {
+    // sort_mode: 0 = scatter + wave sorts, 1 = + block sorts (a bucket beyond KMX_PSORT_CAP),
+    //            2 = the positions already lie sorted in d_region (sort_kmer_positions: a bucket beyond the block sort)
     const uint64_t npos = n - k + 1;
     const unsigned int grid = (unsigned int)std::min<uint64_t>(blocks_for(npos, KMX_BLOCK), 256 * 64);
-    (void)hipMemcpyAsync(d_cursor, d_offs, n_keys * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
-    hipLaunchKernelGGL(k_build_scatter, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_cursor, d_region);
     const unsigned int wblocks = (unsigned int)std::min<uint64_t>((n_keys + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_bucket_sort_wave, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_region);
-    if (block_sort) launch_bucket_sort_block(s, d_offs, n_keys, d_region);
+    if (sort_mode != 2) {
+        (void)hipMemcpyAsync(d_cursor, d_offs, n_keys * sizeof(uint32_t), hipMemcpyDeviceToDevice, s);
+        hipLaunchKernelGGL(k_build_scatter, dim3(grid), dim3(KMX_BLOCK), 0, s, d_text, npos, k, sigma, d_cursor, d_region);
+        hipLaunchKernelGGL(k_bucket_sort_wave, dim3(wblocks ? wblocks : 1), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_region);
+        if (sort_mode == 1) launch_bucket_sort_block(s, d_offs, n_keys, d_region);
+    }
     if (d_aoffs) {
         hipLaunchKernelGGL(k_build_padded, dim3(blocks_for(n_keys, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_offs, n_keys, d_hist, d_info + 1);
         launch_scan(s, d_hist, n_keys, d_bsum, d_scratch_u64, d_total + 1);

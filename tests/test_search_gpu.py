@@ -452,7 +452,7 @@ def test_device_built_index_equals_host_flatten(engine, orc, table):
     c = plain.search(qranks, qoff).host()
     for x, y in zip(a, c):
         assert np.array_equal(x, y)
-    # a text with a bucket beyond the LDS sorts' capacity takes the host fallback for that element
+    # a text with a bucket beyond the LDS sorts' capacity: that element's positions come from sorted (hash, position) pairs
     skew = np.zeros(100_000, np.uint8)
     skew[::3] = 1
     d2 = engine.Index(skew, 4, [6, 3], keep_host_arena=True)
