@@ -518,7 +518,17 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     const bool aligned_copy = !o.no_aligned_copy && !(getenv("KMX_ALIGNED") && atoi(getenv("KMX_ALIGNED")) == 0);
     void* arena = nullptr;   // allocated by install_images_impl once every element's region is known
     DeviceScratch scratch;
-    const uint64_t DEVICE_BUILD_MAX_KEYS = uint64_t(1) << 26;
+    // histogram path: up to 2^30 keys (the dense-table limit) when the device has room for its scratch
+    // (hist + scan + cursors + tables: ~40 B per key), 2^26 otherwise
+    uint64_t DEVICE_BUILD_MAX_KEYS = uint64_t(1) << 26;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            while (DEVICE_BUILD_MAX_KEYS < (uint64_t(1) << 30) && (DEVICE_BUILD_MAX_KEYS << 1) * 40 + n * 24 < free_b / 2) DEVICE_BUILD_MAX_KEYS <<= 1;
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     auto up32 = [](uint64_t v) { return (v + 31) & ~uint64_t(31); };
     uint64_t max_keys = 0;
     std::vector<char> sparse(n_ks, 0);   // key space beyond the histogram: sorted (hash, position) pairs, open table (kmx_build_sort.hip)
@@ -526,8 +536,9 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     for (uint32_t i = 0; i < n_ks; ++i) {
         const uint64_t nk = kmx::key_space(sigma, ks[i]);
         if (o.host_flatten) continue;
-        if (nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
-        else if (kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind) == KMX_TABLE_OPEN) { sparse[i] = 1; any_sparse = true; }
+        const bool open = kmx::resolve_table_kind(sigma, ks[i], n, o.table_kind) == KMX_TABLE_OPEN;
+        if (open && nk > (uint64_t(1) << 26)) { sparse[i] = 1; any_sparse = true; }      // (an open table of a small key space comes from the histogram too)
+        else if (nk <= DEVICE_BUILD_MAX_KEYS) { on_device[i] = 1; max_keys = std::max(max_keys, nk); }
     }
     // per device-built element, filled by phase 1
     struct DevElem { uint32_t* d_offs = nullptr; uint32_t* d_aoffs = nullptr; uint32_t* d_atab = nullptr; uint32_t max_bucket = 0; uint64_t a0 = 0; };

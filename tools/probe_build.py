@@ -10,7 +10,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from kmer_index_amd import engine, synth  # noqa: E402
 
 n = int(float(os.environ.get("N", "1e8")))
-for sigma, ks in ((4, [10]), (4, [16]), (4, [20]), (4, [31]), (5, [14]), (20, [8])):
+for sigma, ks in ((4, [10]), (4, [14]), (4, [15]), (4, [16]), (4, [20]), (4, [31]), (5, [14]), (20, [8])):
     text = synth.ranks(1002, n, sigma)
     row = []
     for host in (False, True):
