@@ -875,7 +875,8 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         });
     HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    r->n_stitch = r->h_ctr[KMX_CTR_STITCH];
+    const uint64_t n_stitch_groups = r->h_ctr[KMX_CTR_STITCH], n_stitch_tiny = r->h_ctr[KMX_CTR_STITCH_TINY];   // front / back of stitch_list
+    r->n_stitch = n_stitch_groups + n_stitch_tiny;
     r->last_had_stitch = r->n_stitch != 0;
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
     r->n_prefix = n_prefix_small + n_prefix_big;
@@ -895,7 +896,10 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
             d.stitch_hits = r->stitch_hits.as<uint32_t>();
         else
             (void)hipGetLastError();
-        timed(ix, K_VALIDATE, s, [&] { kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, r->n_stitch, n_more, r->mask_words.as<uint64_t>()); });
+        timed(ix, K_VALIDATE, s, [&] {
+            kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, n_stitch_groups, n_more, n_stitch_tiny, d.stitch_list + (nq - n_stitch_tiny),
+                                 r->mask_words.as<uint64_t>());
+        });
         scan_hits();
         HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
@@ -920,7 +924,14 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
         });
     }
     if (r->n_stitch && !d.stitch_hits)
-        timed(ix, K_COMPACT, s, [&] { kmx::launch_compact(s, ix->d_arena, d, r->n_stitch, r->mask_words.as<uint64_t>(), hit_off, out); });
+        timed(ix, K_COMPACT, s, [&] {
+            if (n_stitch_groups) kmx::launch_compact(s, ix->d_arena, d, n_stitch_groups, r->mask_words.as<uint64_t>(), hit_off, out);
+            if (n_stitch_tiny) {
+                kmx::QueryDesc dt = d;
+                dt.stitch_list = d.stitch_list + (nq - n_stitch_tiny);
+                kmx::launch_compact(s, ix->d_arena, dt, n_stitch_tiny, r->mask_words.as<uint64_t>(), hit_off, out);
+            }
+        });
 
     // PREFIX work list: small queries from the front of prefix_list, the others from its back
     kmx::QueryDesc d_big = d;

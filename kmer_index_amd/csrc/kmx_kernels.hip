@@ -8,6 +8,7 @@
 //                   part's bucket staged in LDS (:270-298, :532-555) -> compressed_bitset mask words via
 //                   ballot + the compacted survivors
 //  [k_validate_more] queries with more parts: the survivors against every part, one part per lane
+//  [k_validate_tiny] STITCH queries with a handful of candidates (large k): one thread per query does all of it
 //   k_scan_*        exclusive scan of the per-query hit counts -> hit_off
 //   k_partition     first query of every output tile
 //   k_fill          output-centric copy of bucket runs -> to_vector() lists
@@ -199,10 +200,10 @@ __device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_prefix, n_prefix_big, n_error, n_none, n_more;
+    unsigned int n_stitch, n_stitch_tiny, n_prefix, n_prefix_big, n_error, n_none, n_more;
     unsigned long long words, pelems;
     unsigned int max_runs;
-    unsigned int base_stitch, base_prefix, base_prefix_big;
+    unsigned int base_stitch, base_stitch_tiny, base_prefix, base_prefix_big;
     unsigned long long base_words;
 };
 
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
+        bc.n_stitch = bc.n_stitch_tiny = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = 0;
         bc.max_runs = 0;
     }
@@ -480,8 +481,12 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     unsigned int loc = 0;
     unsigned long long loc_words = 0;
     if (my_stitch) {
-        if (p1 & KMX_P1_MORE) atomicAdd(&bc.n_more, 1u);
-        loc = atomicAdd(&bc.n_stitch, 1u);
+        if (c0 <= KMX_VTINY && uint32_t(p1) <= KMX_VTINY) {
+            loc = atomicAdd(&bc.n_stitch_tiny, 1u) | 0x80000000u;    // tiny: one thread validates it, listed from the back
+        } else {
+            if (p1 & KMX_P1_MORE) atomicAdd(&bc.n_more, 1u);
+            loc = atomicAdd(&bc.n_stitch, 1u);
+        }
         loc_words = atomicAdd(&bc.words, my_words);
     }
     if (my_prefix) {
@@ -520,8 +525,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (bc.n_stitch) {
-            bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
+        if (bc.n_stitch | bc.n_stitch_tiny) {
+            if (bc.n_stitch) bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
+            if (bc.n_stitch_tiny) bc.base_stitch_tiny = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH_TINY], (unsigned long long)bc.n_stitch_tiny);
             bc.base_words = atomicAdd(&ctr[KMX_CTR_MASK_WORDS], bc.words);
             if (bc.n_more) atomicAdd(&ctr[KMX_CTR_STITCH_MORE], (unsigned long long)bc.n_more);
         }
@@ -540,7 +546,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
         if (kinds[it] == KMX_KIND_STITCH) {
             d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
-            d.stitch_list[bc.base_stitch + locs[it]] = uint32_t(q);
+            if (locs[it] & 0x80000000u) d.stitch_list[nq - 1 - (bc.base_stitch_tiny + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
+            else d.stitch_list[bc.base_stitch + locs[it]] = uint32_t(q);
         } else if (kinds[it] == KMX_KIND_PREFIX) {
             if (locs[it] & 0x80000000u) d.prefix_list[nq - 1 - (bc.base_prefix_big + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
             else d.prefix_list[bc.base_prefix + locs[it]] = uint32_t(q);
@@ -575,7 +582,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 // e-th summand of _optimal_nk_sum[m] counted from the end (:532-555).  Returns this lane's verdict.
 __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
                                                   const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff,
-                                                  uint32_t q, uint32_t p, uint32_t gl)
+                                                  uint32_t q, uint32_t p, uint32_t gl, uint32_t stride = KMX_VGROUP)
 {
     const uint64_t b = qoff[q];
     const uint64_t m = qoff[q + 1] - b;
@@ -589,7 +596,7 @@ __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict_
         const uint32_t k = el->k;
         const uint32_t P = uint32_t(m / k);
         const uint32_t n_extra = P - 1 + ((m % k) ? 1 : 0);
-        for (uint32_t e = gl; e < n_extra && good; e += KMX_VGROUP) {
+        for (uint32_t e = gl; e < n_extra && good; e += stride) {
             const uint64_t start = (e < P - 1) ? uint64_t(e + 1) * k : (m - k);
             uint64_t h;
             rank_hash(qr + start, k, sigma, h, qend);
@@ -602,7 +609,7 @@ __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict_
         const uint32_t n_extra = pe.nparts - 1u;
         uint64_t mm = m;                                               // the walk resumes where this lane stopped
         uint32_t walked = 0;
-        for (uint32_t e = gl; e < n_extra && good; e += KMX_VGROUP) {
+        for (uint32_t e = gl; e < n_extra && good; e += stride) {
             const KmxElemDev* __restrict__ el = nullptr;
             uint32_t k = 0;
             for (; walked <= e; ++walked) {
@@ -772,6 +779,47 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         __builtin_amdgcn_wave_barrier();                                // stage[] is reused by the next round
 
     }
+}
+
+// k_validate_tiny — STITCH queries with at most KMX_VTINY candidates and KMX_VTINY entries in the filter part's bucket
+// (the regime of a large k: buckets of about one position, e.g. reads against a k = 20 index): one THREAD per query
+// does everything — filter by a linear scan, the further parts one after the other for the few survivors, the one
+// mask word, the survivor list, the count.  A 16-lane group per query would idle 15 lanes there.
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate_tiny(const KmxIndexDev* __restrict__ ix,
+                                                             const uint32_t* __restrict__ arena,
+                                                             const uint8_t* __restrict__ qranks,
+                                                             const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                             const uint32_t* __restrict__ list, uint64_t n_tiny,
+                                                             uint64_t* __restrict__ mask_words)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (i >= n_tiny) return;
+    const uint32_t q = list[i];
+    const uint32_t c0 = d.c0[q];
+    const uint64_t src = d.src[q] & ~SRC_FLAGS;
+    const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
+    const bool more = (p1 & KMX_P1_MORE) != 0;
+    const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & 0x7FFFFFFFu;
+    uint32_t filt[KMX_VTINY];
+#pragma unroll
+    for (uint32_t t = 0; t < KMX_VTINY; ++t) filt[t] = arena[t < pcnt ? p1src + t : p1src];      // straight-line loads
+    uint64_t word = 0;
+    uint32_t valid = 0;
+    for (uint32_t ci = 0; ci < c0; ++ci) {
+        const uint32_t p = arena[src + ci];
+        const uint32_t x = p + delta;
+        bool hit = false;
+#pragma unroll
+        for (uint32_t t = 0; t < KMX_VTINY; ++t) hit |= t < pcnt && filt[t] == x;                  // binary_search :283, lower_bound :544-546
+        if (hit && more) hit = stitch_parts_hold(ix, arena, qranks, qoff, q, p, 0u, 1u);
+        if (hit) {
+            word |= uint64_t(1) << ci;                                                             // bit i = word i>>6, bit i&63
+            if (d.stitch_hits) d.stitch_hits[wbase * 64 + valid] = p;
+            ++valid;
+        }
+    }
+    mask_words[wbase] = word;                                                                      // c0 <= KMX_VTINY < 64: one word (compressed_bitset.hpp:23)
+    d.cnt[q] = valid;
 }
 
 // k_validate_more — STITCH queries with further parts beyond the filter of k_validate<false>: every survivor
@@ -1426,11 +1474,17 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
     hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
 }
 
-// n_more = STITCH queries with further parts beyond the filter part.  With a survivor buffer (d.stitch_hits) those are
-// finished by k_validate_more from the survivor lists; without one k_validate checks them in line.
+// The STITCH work list holds n_stitch queries from its front and n_tiny "tiny" ones from its back (list_end = one past
+// the last entry of the buffer).  n_more = queries of the front list with further parts beyond the filter part: with a
+// survivor buffer (d.stitch_hits) those are finished by k_validate_more from the survivor lists, without one k_validate
+// checks them in line.
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
-                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t* mask_words)
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words)
 {
+    if (n_tiny)
+        hipLaunchKernelGGL(k_validate_tiny, dim3(blocks_for(n_tiny, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, arena, qranks, qoff, d, tiny_list,
+                           n_tiny, mask_words);
+    if (!n_stitch) return;
     uint64_t waves = (n_stitch + KMX_VGROUPS - 1) / KMX_VGROUPS;        // KMX_VGROUPS queries per wave
     unsigned int blocks = (unsigned int)std::min<uint64_t>((waves + 3) / 4, 256 * 32);
     const dim3 grid(blocks ? blocks : 1), block(KMX_BLOCK);
