@@ -40,6 +40,9 @@ def main():
                          "(default, zero data-path collective); hits: RCCL gatherv of every hit list to rank 0 inside each step")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams (and result handles) the steps alternate over; >1 lets step i+1's lookup/scan overlap step i's fill")
+    ap.add_argument("--pipeline", type=int, default=2,
+                    help="result handles the steps rotate over on ONE stream with KMX_SEARCH_ASYNC: the host enqueues step i+1 while "
+                         "step i runs and reads step i's counters when its handle comes round again (1 = every step waits for its own)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
@@ -112,15 +115,17 @@ def main():
     torch.cuda.synchronize()
 
     n_streams = max(1, args.streams)
+    depth = max(1, args.pipeline) if n_streams == 1 else 1
     t_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
-    results = [engine.Result() for _ in range(n_streams)]
+    results = [engine.Result() for _ in range(max(n_streams, depth))]
     res = results[0]
     step_no = [0]
+    step_flags = engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT
 
     def step():
-        i = step_no[0] % n_streams
+        i = step_no[0] % len(results)
         step_no[0] += 1
-        idx.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=t_streams[i].cuda_stream, result=results[i])
+        idx.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=step_flags, stream=t_streams[i % n_streams].cuda_stream, result=results[i])
         if world > 1 and args.gather == "hits":
             with torch.cuda.stream(t_streams[i]):
                 t_off, t_pos = results[i].device_tensors(dev)
@@ -128,6 +133,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    for r_ in results:
+        r_.counts()                                   # no warmup step is left pending into the timed region
     torch.cuda.synchronize()
     idx.stats_enable(True)
     idx.stats_reset()
@@ -137,6 +144,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    for r_ in results:
+        r_.counts()                                   # completes a step that is still pending on its handle (inside the timed region)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -260,7 +269,7 @@ def main():
                                    f"(lengths {qlens}, planted share {planted}), materialised sorted position lists (to_vector), table={args.table}"
                                    f"{'(dense)' if info['tables'][0] == engine.TABLE_DENSE else '(open)'}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
-                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated", "gather": args.gather, "streams": n_streams},
+                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated", "gather": args.gather, "streams": n_streams, "pipeline_depth": depth},
             "roofline": {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),

@@ -85,6 +85,11 @@ typedef struct kmx_options {
 #define KMX_SEARCH_DEFAULT 0u
 #define KMX_SEARCH_KEEP_MASKS 1u   /* keep candidate runs + compressed_bitset mask words for STITCH queries */
 #define KMX_SEARCH_COUNT_ONLY 2u   /* stop after hit_off (no position lists are materialised)              */
+#define KMX_SEARCH_ASYNC 4u        /* device form only: return once the first half of the search is enqueued (lookup,
+                                      scan, the steady-state fill) without waiting for the counters; the search is
+                                      completed by whatever touches the result next (counts / view / masks / free / a
+                                      new search into it).  The index, d_qranks and d_qoff must stay alive until then.
+                                      Two results used in turn keep the GPU busy across batches. */
 
 typedef struct kmx_index kmx_index;
 typedef struct kmx_result kmx_result;

@@ -184,6 +184,17 @@ struct kmx_index {
     Stats stats;
 };
 
+// What search_finish needs from the call that enqueued the first half of a search.
+struct SearchCtx {
+    kmx_index* ix = nullptr;
+    const uint8_t* qr = nullptr;
+    const uint64_t* qo = nullptr;
+    hipStream_t s = nullptr;
+    uint64_t tile_cap = 0, spec_tiles = 0;
+    bool spec_fill = false;
+    bool pending = false;
+};
+
 struct kmx_result {
     const kmx_index* index = nullptr;   // identity only: never dereferenced after the search call returns
     int device = 0;
@@ -201,6 +212,8 @@ struct kmx_result {
     bool host_valid = false, host_masks_valid = false;
     bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
     std::shared_ptr<ResultPool> pool;      // where kmx_result_free parks this result (set by the search that made it)
+    SearchCtx ctx;                         // the half-done search of a KMX_SEARCH_ASYNC call (search_finish completes it)
+    hipEvent_t done = nullptr;             // recorded behind the first half's counter read-back
     bool quiesced = true;                  // no kernel of the last search can still be running on `stream`
 
     size_t device_bytes() const
@@ -221,6 +234,8 @@ struct kmx_result {
             b->release();
         if (h_ctr) (void)hipHostFree(h_ctr);
         h_ctr = nullptr;
+        if (done) (void)hipEventDestroy(done);
+        done = nullptr;
     }
 };
 
@@ -629,6 +644,10 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     {
         hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
         if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); }
+        // the padding between line-aligned groups is never written by the build kernels: defined contents (the image on
+        // disk and the host mirror of the arena see it)
+        e = hipMemset(arena, 0, arena_elems * 4 + 64);
+        if (e != hipSuccess) { free_dev(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("arena: ") + hipGetErrorString(e)); }
     }
     auto free_sparse = [&] {
         for (auto& im : images) {
@@ -796,6 +815,8 @@ kmx_status kmx_stats_reset(kmx_index* ix)
     return KMX_OK;
 }
 
+static kmx_status search_finish(kmx_result* r);
+
 kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, const void* d_qoff, uint64_t nq,
                                    uint32_t flags, void* stream, kmx_result** inout)
 {
@@ -810,6 +831,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
 
     kmx_result* r = *inout;
     if (!r) { r = take_result(ix); *inout = r; }
+    else if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }   // its buffers are about to be reused
     r->index = ix;
     r->device = ix->device;
     r->stream = s;
@@ -874,7 +896,48 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
                              ctr + KMX_CTR_TOTAL_HITS, spec_tiles, d, r->out.as<uint32_t>());
         });
     HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
+    // everything after the read-back lives in search_finish: right away, or (KMX_SEARCH_ASYNC) when the result is next touched
+    r->ctx = SearchCtx{ix, qr, qo, s, tile_cap, spec_tiles, spec_fill, true};
+    if (flags & KMX_SEARCH_ASYNC) {
+        if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(r->done, s));
+        return KMX_OK;
+    }
+    return search_finish(r);
+}
+
+// Second half of a search: waits for the counters of the first half, then validates / fills / sorts whatever the
+// speculative steady-state path has not already done.  A no-op when nothing is pending.
+static kmx_status search_finish(kmx_result* r)
+{
+    if (!r->ctx.pending) return KMX_OK;
+    r->ctx.pending = false;
+    kmx_index* ix = r->ctx.ix;
+    const uint8_t* qr = r->ctx.qr;
+    const uint64_t* qo = r->ctx.qo;
+    hipStream_t s = r->ctx.s;
+    const uint64_t nq = r->nq, tile_cap = r->ctx.tile_cap, spec_tiles = r->ctx.spec_tiles;
+    const uint32_t flags = r->flags;
+    const bool spec_fill = r->ctx.spec_fill;
+    HIP_TRY(hipSetDevice(r->device));
+    if (r->done && (flags & KMX_SEARCH_ASYNC)) HIP_TRY(hipEventSynchronize(r->done));
+    else HIP_TRY(hipStreamSynchronize(s));
+    kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
+                     r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
+                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
+    auto* ctr = r->ctr.as<unsigned long long>();
+    const KmxIndexDev* dix = ix->d_index;
+    const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
+    const uint64_t tile = kmx::fill_tile(fv);
+    auto scan_hits = [&] {
+        timed(ix, K_SCAN, s, [&] {
+            if (tile_cap >= 2)
+                kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS,
+                                       tile, tile_cap - 1, r->tile_q.as<uint32_t>());
+            else
+                kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
+        });
+    };
     const uint64_t n_stitch_groups = r->h_ctr[KMX_CTR_STITCH], n_stitch_tiny = r->h_ctr[KMX_CTR_STITCH_TINY];   // front / back of stitch_list
     r->n_stitch = n_stitch_groups + n_stitch_tiny;
     r->last_had_stitch = r->n_stitch != 0;
@@ -989,7 +1052,7 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     HIP_TRY(r->in_qoff.ensure((nq + 1) * 8));
     if (n_letters) HIP_TRY(hipMemcpyAsync(r->in_qranks.p, qranks, n_letters, hipMemcpyHostToDevice, ix->stream));
     if (nq) HIP_TRY(hipMemcpyAsync(r->in_qoff.p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-    kmx_status st = kmx_search_batch_device(ix, r->in_qranks.p, r->in_qoff.p, nq, flags, ix->stream, out);
+    kmx_status st = kmx_search_batch_device(ix, r->in_qranks.p, r->in_qoff.p, nq, flags & ~KMX_SEARCH_ASYNC, ix->stream, out);
     if (st != KMX_OK) return st;
     HIP_TRY(hipStreamSynchronize(ix->stream));
     r->quiesced = true;
@@ -1000,6 +1063,7 @@ kmx_status kmx_result_counts(const kmx_result* r, uint64_t* nq, uint64_t* n_hits
                              uint64_t* n_prefix, uint64_t* n_error)
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_counts: result is NULL");
+    if (r->ctx.pending) { kmx_status fs = search_finish(const_cast<kmx_result*>(r)); if (fs != KMX_OK) return fs; }
     if (nq) *nq = r->nq;
     if (n_hits) *n_hits = r->n_hits;
     if (n_exact) *n_exact = r->n_exact;
@@ -1013,6 +1077,7 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
                                   const uint8_t** d_status)
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: result is NULL");
+    if (r->ctx.pending) { kmx_status fs = search_finish(const_cast<kmx_result*>(r)); if (fs != KMX_OK) return fs; }
     if (d_hit_off) *d_hit_off = r->hit_off.as<uint64_t>();
     if (d_positions) *d_positions = r->out.as<uint32_t>();
     if (d_status) *d_status = r->status.as<uint8_t>();
@@ -1023,6 +1088,7 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
                            const uint8_t** kinds)
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view: result is NULL");
+    if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
     if (!r->host_valid) {
         HIP_TRY(hipSetDevice(r->device));
         const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
@@ -1072,6 +1138,7 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
                             const uint32_t** cand_count, const uint64_t** cand_src)
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: result is NULL");
+    if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
     if (!(r->flags & KMX_SEARCH_KEEP_MASKS)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: search ran without KMX_SEARCH_KEEP_MASKS");
     if (!r->host_masks_valid) {
         HIP_TRY(hipSetDevice(r->device));
@@ -1099,6 +1166,7 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
 void kmx_result_free(kmx_result* r)
 {
     if (!r) return;
+    if (r->ctx.pending) (void)search_finish(r);
     if (r->pool && r->device_bytes() <= kPoolMaxBytes) {
         if (!r->quiesced) {                                  // its buffers are about to serve another stream
             (void)hipSetDevice(r->device);

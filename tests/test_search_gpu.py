@@ -176,6 +176,53 @@ def test_largest_valid_k_of_an_alphabet(engine, orc, sigma, k):
             assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, q))
 
 
+def test_async_searches_rotate_over_two_results(engine, orc):
+    """KMX_SEARCH_ASYNC: the call returns with the first half of the search enqueued; the next touch of the result
+    completes it.  Two results in rotation over batches of every kind mix (the second halves — validation, sorts,
+    re-fills — then run behind the next batch's first half) must give what the synchronous calls give."""
+    import torch
+    text = synth.ranks(31, 400_000, 4)
+    ks = [6, 9, 12]
+    idx = engine.Index(text, 4, ks)
+    dev = torch.device("cuda", 0)
+    stream = torch.cuda.Stream(device=dev)
+    batches = []
+    for b in range(7):
+        lens = [[9], [9, 12], [4, 5], [18, 21, 24, 30], [2, 6, 9, 13, 27, 40], [12], [9, 9, 9, 17]][b]
+        qr, qo = synth.mixed_queries(400 + b, text, [3000, 1, 800, 5000, 2500, 20000, 64][b], lens, 4)
+        batches.append((qr, qo, torch.from_numpy(qr).to(dev), torch.from_numpy(qo.view(np.int64)).to(dev)))
+    want = [idx.search(qr, qo).host() for qr, qo, _, _ in batches]
+    results = [engine.Result(), engine.Result()]
+    inflight = [None, None]
+    for rnd in range(3):
+        for b, (qr, qo, d_q, d_o) in enumerate(batches):
+            slot = (rnd * len(batches) + b) % 2
+            if inflight[slot] is not None:                       # collect the batch this handle still holds, then reuse it
+                got = results[slot].host()
+                for x, y in zip(got, want[inflight[slot]]):
+                    assert np.array_equal(x, y), (rnd, b, inflight[slot])
+            idx.search_device(d_q.data_ptr(), d_o.data_ptr(), qo.size - 1, flags=engine.SEARCH_ASYNC, stream=stream.cuda_stream,
+                              result=results[slot])
+            inflight[slot] = b
+    for slot in range(2):
+        c = results[slot].counts()                                # counts alone complete a pending search
+        assert c["n_hits"] == int(want[inflight[slot]][0][-1])
+        got = results[slot].host()
+        for x, y in zip(got, want[inflight[slot]]):
+            assert np.array_equal(x, y)
+    # a pending result may simply be released, or searched into again without having been read
+    idx.search_device(batches[3][2].data_ptr(), batches[3][3].data_ptr(), batches[3][1].size - 1, flags=engine.SEARCH_ASYNC,
+                      stream=stream.cuda_stream, result=results[0])
+    idx.search_device(batches[5][2].data_ptr(), batches[5][3].data_ptr(), batches[5][1].size - 1, flags=engine.SEARCH_ASYNC,
+                      stream=stream.cuda_stream, result=results[0])
+    for x, y in zip(results[0].host(), want[5]):
+        assert np.array_equal(x, y)
+    idx.search_device(batches[4][2].data_ptr(), batches[4][3].data_ptr(), batches[4][1].size - 1, flags=engine.SEARCH_ASYNC,
+                      stream=stream.cuda_stream, result=results[1])
+    results[1].close()
+    torch.cuda.synchronize()
+
+
 def test_pooled_results_and_results_that_outlive_their_index(engine, orc):
     """kmx_result_free parks results in the index's pool; a later search without a result of its own takes one over
     (buffers of another batch, possibly of another size and kind mix).  A result may be released after its index."""
