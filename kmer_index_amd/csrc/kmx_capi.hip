@@ -105,7 +105,7 @@ enum KernelId {
     K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
-    "k_lookup", "k_scan(reduce+spine+down)", "k_partition", "k_fill", "k_validate", "k_compact",
+    "k_lookup", "k_scan(reduce+down)", "k_partition", "k_fill", "k_validate", "k_compact",
     "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block"};
 
 struct Stats {

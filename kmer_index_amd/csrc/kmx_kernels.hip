@@ -932,11 +932,16 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_spine(uint64_t* __restrict__
 // owns output slots [ex, ex + v); every tile boundary t*tile inside that range gets tile_q[t] = i
 // (the last query whose offset is <= the boundary), and tile_q[t] for boundaries at or past the
 // total is n - 1.
-template <bool TILES>
+//
+// SPINE: there is no spine launch — bsum holds the plain block sums of k_scan_reduce and every block adds up the
+// sums in front of it itself (at most KMX_SCAN_FUSED_SPINE_BLOCKS of them: a few KB out of L2); the last block
+// also writes the grand total.
+template <bool TILES, bool SPINE>
 __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restrict__ in, uint64_t n,
                                                          const uint64_t* __restrict__ bsum,
                                                          uint64_t* __restrict__ out, uint64_t tile,
-                                                         uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q)
+                                                         uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q,
+                                                         unsigned long long* __restrict__ total_out)
 {
     // The block's 4096 items as KMX_SCAN_ROWS rows of 1024: in row r thread t owns items r*1024 + 4t .. 4t+3 —
     // one coalesced 16-byte load and two 16-byte stores per row.  The rows are scanned together (one set of
@@ -974,7 +979,21 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
         for (int r = 0; r < ROWS; ++r) wave_sum[r][w] = inc[r];
     }
     __syncthreads();
-    uint64_t row_base = bsum[blockIdx.x];
+    uint64_t row_base;
+    if constexpr (SPINE) {
+        __shared__ uint64_t part[KMX_BLOCK / KMX_WAVE];
+        uint64_t acc = 0;
+        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += KMX_BLOCK) acc += bsum[i];
+        for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (lane == 0) part[w] = acc;
+        __syncthreads();
+        row_base = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i) row_base += part[i];
+        if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) *total_out = row_base + bsum[blockIdx.x];
+    } else {
+        row_base = bsum[blockIdx.x];
+    }
 #pragma unroll
     for (int r = 0; r < ROWS; ++r) {
         uint64_t carry = 0, total = 0;
@@ -1498,13 +1517,21 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
 
 uint64_t scan_blocks(uint64_t n) { return blocks_for(n, KMX_SCAN_TILE); }
 
+#define KMX_SCAN_FUSED_SPINE_BLOCKS 8192     // up to this many blocks the downsweep adds up the block sums itself
+
 void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
                  unsigned long long* total_out)
 {
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
+    if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
+        hipLaunchKernelGGL((k_scan_down<false, true>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
+                           (uint32_t*)nullptr, total_out);
+        return;
+    }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL(k_scan_down<false>, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0), (uint32_t*)nullptr);
+    hipLaunchKernelGGL((k_scan_down<false, false>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
+                       (uint32_t*)nullptr, total_out);
 }
 
 // scan + first-query-of-every-tile in one downsweep; tile_q must hold n_tiles_cap + 1 entries
@@ -1513,8 +1540,12 @@ void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* 
 {
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
+    if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
+        hipLaunchKernelGGL((k_scan_down<true, true>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out);
+        return;
+    }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL(k_scan_down<true>, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q);
+    hipLaunchKernelGGL((k_scan_down<true, false>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out);
 }
 
 // fill variants, selected at run time (KMX_FILL_VARIANT, see kmx_capi.hip)
