@@ -105,7 +105,7 @@ enum KernelId {
     K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
-    "k_lookup", "k_scan(reduce+down)", "k_partition", "k_fill", "k_validate", "k_compact",
+    "k_lookup", "k_scan", "k_partition", "k_fill", "k_validate", "k_compact",
     "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block"};
 
 struct Stats {
@@ -857,7 +857,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->status.ensure(nq));
     HIP_TRY(r->stitch_list.ensure(nq * 4));
     HIP_TRY(r->prefix_list.ensure(nq * 4));
-    HIP_TRY(r->bsum.ensure(kmx::scan_blocks(nq) * 8));
+    HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(nq), kmx::lookup_blocks(nq)) * 8));
     HIP_TRY(r->ctr.ensure(KMX_CTR_COUNT * sizeof(unsigned long long)));
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
@@ -866,23 +866,18 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     const KmxIndexDev* dix = ix->d_index;
 
     HIP_TRY(hipMemsetAsync(ctr, 0, KMX_CTR_COUNT * sizeof(unsigned long long), s));
-    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr); });
+    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>()); });
     // speculative scan: already final when the batch holds no STITCH query
     // The downsweep also records the first query of every output tile (k_partition's job) when the
     // tile table kept from an earlier batch is large enough — the steady state.
     const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
     const uint64_t tile = kmx::fill_tile(fv);
     const uint64_t tile_cap = r->tile_q.cap / 4;            // entries available while the scan runs
-    auto scan_hits = [&] {
-        timed(ix, K_SCAN, s, [&] {
-            if (tile_cap >= 2)
-                kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS,
-                                       tile, tile_cap - 1, r->tile_q.as<uint32_t>());
-            else
-                kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
-        });
-    };
-    scan_hits();
+    // the block sums k_lookup left in bsum are the first level of this scan
+    timed(ix, K_SCAN, s, [&] {
+        kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS, tile,
+                               tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, true);
+    });
     // Steady state (tile table and output buffer kept from an earlier batch): k_fill goes out right behind the
     // scan, before the host knows the hit total — it reads the total from device memory and its grid is sized
     // from what the buffers can hold.  Valid whenever the batch holds no STITCH query (their counts come later)
@@ -929,13 +924,10 @@ static kmx_status search_finish(kmx_result* r)
     const KmxIndexDev* dix = ix->d_index;
     const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
     const uint64_t tile = kmx::fill_tile(fv);
-    auto scan_hits = [&] {
+    auto scan_hits = [&] {                                     // (k_validate changed the counts: a full scan)
         timed(ix, K_SCAN, s, [&] {
-            if (tile_cap >= 2)
-                kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS,
-                                       tile, tile_cap - 1, r->tile_q.as<uint32_t>());
-            else
-                kmx::launch_scan(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS);
+            kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS, tile,
+                                   tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, false);
         });
     };
     const uint64_t n_stitch_groups = r->h_ctr[KMX_CTR_STITCH], n_stitch_tiny = r->h_ctr[KMX_CTR_STITCH_TINY];   // front / back of stitch_list

@@ -23,8 +23,9 @@ struct QueryDesc {
                             // k_validate and copied out by k_fill; nullptr -> k_compact decodes the masks instead
 };
 
+uint64_t lookup_blocks(uint64_t nq);
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
-                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr);
+                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits);
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);
@@ -54,7 +55,7 @@ struct FillVariant {
     bool nt;
 };
 void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
-                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q);
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums);
 FillVariant effective_fill_variant(const FillVariant& v, bool rec32);
 uint64_t fill_tile(const FillVariant& v);
 void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q);

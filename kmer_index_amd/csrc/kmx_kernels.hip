@@ -201,7 +201,7 @@ __device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_
 // ---------------------------------------------------------------------------
 struct BlockCounters {
     unsigned int n_stitch, n_stitch_tiny, n_prefix, n_prefix_big, n_error, n_none, n_more;
-    unsigned long long words, pelems;
+    unsigned long long words, pelems, hits;
     unsigned int max_runs;
     unsigned int base_stitch, base_stitch_tiny, base_prefix, base_prefix_big;
     unsigned long long base_words;
@@ -210,13 +210,16 @@ struct BlockCounters {
 __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restrict__ ix,
                                                       const uint8_t* __restrict__ qranks,
                                                       const uint64_t* __restrict__ qoff, uint64_t nq,
-                                                      QueryDesc d, unsigned long long* __restrict__ ctr)
+                                                      QueryDesc d, unsigned long long* __restrict__ ctr,
+                                                      uint64_t* __restrict__ block_hits)
 {
+    // block_hits[blockIdx.x] = sum of the block's hit counts: the first level of the scan that follows (k_scan_reduce's
+    // job, for free here)
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
         bc.n_stitch = bc.n_stitch_tiny = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
-        bc.words = bc.pelems = 0;
+        bc.words = bc.pelems = bc.hits = 0;
         bc.max_runs = 0;
     }
     {
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     unsigned int locs[KMX_LOOKUP_ITEMS];
     unsigned long long locw[KMX_LOOKUP_ITEMS];
     bool done[KMX_LOOKUP_ITEMS];
+    uint64_t my_hits = 0;
 
     // ---- pass 1: the plain exact lookup (m == k <= 16, :198-205), the thread's queries INTERLEAVED:
     // all offsets, then all plan entries, then all letter loads, then all probes — one memory round
@@ -332,6 +336,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             d.cnt[q] = cnt;
             d.kind[q] = kind;
             d.status[q] = status;
+            my_hits += cnt;
         }
         if (n_err) atomicAdd(&bc.n_error, n_err);
         if (n_none) atomicAdd(&bc.n_none, n_none);
@@ -507,6 +512,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     locs[it] = loc;
     locw[it] = loc_words;
     if (q < nq) {
+        my_hits += cnt;
         d.src[q] = kind == KMX_KIND_STITCH ? (src | SRC_SLOW) : (kind == KMX_KIND_PREFIX ? (src | SRC_FLAGS) : src);
         d.cnt[q] = cnt;
         d.kind[q] = kind;
@@ -523,8 +529,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     }
     }   // items
 
+    for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_xor(my_hits, off);
+    if (lane_id() == 0 && my_hits) atomicAdd(&bc.hits, (unsigned long long)my_hits);
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (block_hits) block_hits[blockIdx.x] = bc.hits;
         if (bc.n_stitch | bc.n_stitch_tiny) {
             if (bc.n_stitch) bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
             if (bc.n_stitch_tiny) bc.base_stitch_tiny = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH_TINY], (unsigned long long)bc.n_stitch_tiny);
@@ -936,13 +945,17 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_spine(uint64_t* __restrict__
 // SPINE: there is no spine launch — bsum holds the plain block sums of k_scan_reduce and every block adds up the
 // sums in front of it itself (at most KMX_SCAN_FUSED_SPINE_BLOCKS of them: a few KB out of L2); the last block
 // also writes the grand total.
-template <bool TILES, bool SPINE>
+// SPINE == 2: the same with the sums k_lookup left behind, one per KMX_BLOCK * KMX_LOOKUP_ITEMS queries (n_fine of
+// them, KMX_SCAN_FINE per scan tile) — no reduce launch either.
+#define KMX_SCAN_FINE (KMX_SCAN_TILE / (KMX_BLOCK * KMX_LOOKUP_ITEMS))
+template <bool TILES, int SPINE>
 __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restrict__ in, uint64_t n,
                                                          const uint64_t* __restrict__ bsum,
                                                          uint64_t* __restrict__ out, uint64_t tile,
                                                          uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q,
-                                                         unsigned long long* __restrict__ total_out)
+                                                         unsigned long long* __restrict__ total_out, uint64_t n_fine)
 {
+    static_assert(KMX_SCAN_TILE % (KMX_BLOCK * KMX_LOOKUP_ITEMS) == 0, "a scan tile is a whole number of lookup blocks");
     // The block's 4096 items as KMX_SCAN_ROWS rows of 1024: in row r thread t owns items r*1024 + 4t .. 4t+3 —
     // one coalesced 16-byte load and two 16-byte stores per row.  The rows are scanned together (one set of
     // wave shuffles and barriers for all of them).
@@ -980,17 +993,23 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
     }
     __syncthreads();
     uint64_t row_base;
-    if constexpr (SPINE) {
+    if constexpr (SPINE != 0) {
         __shared__ uint64_t part[KMX_BLOCK / KMX_WAVE];
+        const uint64_t mine = SPINE == 2 ? uint64_t(blockIdx.x) * KMX_SCAN_FINE : uint64_t(blockIdx.x);   // sums in front of this block
         uint64_t acc = 0;
-        for (uint32_t i = threadIdx.x; i < blockIdx.x; i += KMX_BLOCK) acc += bsum[i];
+        for (uint64_t i = threadIdx.x; i < mine; i += KMX_BLOCK) acc += bsum[i];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
         if (lane == 0) part[w] = acc;
         __syncthreads();
         row_base = 0;
 #pragma unroll
         for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i) row_base += part[i];
-        if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) *total_out = row_base + bsum[blockIdx.x];
+        if (blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {
+            uint64_t own = 0;
+            if constexpr (SPINE == 2) { for (uint64_t i = mine; i < n_fine; ++i) own += bsum[i]; }
+            else own = bsum[blockIdx.x];
+            *total_out = row_base + own;
+        }
     } else {
         row_base = bsum[blockIdx.x];
     }
@@ -1487,10 +1506,13 @@ static inline unsigned int blocks_for(uint64_t n, uint64_t per_block)
     return (unsigned int)(b ? b : 1);
 }
 
+uint64_t lookup_blocks(uint64_t nq) { return blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS); }
+
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
-                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr)
+                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits)
 {
-    hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr);
+    hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr,
+                       block_hits);
 }
 
 // The STITCH work list holds n_stitch queries from its front and n_tiny "tiny" ones from its back (list_end = one past
@@ -1525,27 +1547,38 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, 
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
-        hipLaunchKernelGGL((k_scan_down<false, true>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                           (uint32_t*)nullptr, total_out);
+        hipLaunchKernelGGL((k_scan_down<false, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
+                           (uint32_t*)nullptr, total_out, uint64_t(0));
         return;
     }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL((k_scan_down<false, false>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                       (uint32_t*)nullptr, total_out);
+    hipLaunchKernelGGL((k_scan_down<false, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
+                       (uint32_t*)nullptr, total_out, uint64_t(0));
 }
 
-// scan + first-query-of-every-tile in one downsweep; tile_q must hold n_tiles_cap + 1 entries
+// scan + first-query-of-every-tile in one downsweep; tile_q must hold n_tiles_cap + 1 entries (nullptr: plain scan).
+// lookup_sums: bsum already holds k_lookup's per-block sums of `in` (lookup_blocks(n) of them) — no reduce launch.
 void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
-                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q)
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums)
 {
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
+    if (lookup_sums && nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
+        const uint64_t n_fine = lookup_blocks(n);
+        if (tile_q)
+            hipLaunchKernelGGL((k_scan_down<true, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, n_fine);
+        else
+            hipLaunchKernelGGL((k_scan_down<false, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
+                               (uint32_t*)nullptr, total_out, n_fine);
+        return;
+    }
+    if (!tile_q) { launch_scan(s, in, n, bsum, out, total_out); return; }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
-        hipLaunchKernelGGL((k_scan_down<true, true>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out);
+        hipLaunchKernelGGL((k_scan_down<true, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0));
         return;
     }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL((k_scan_down<true, false>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out);
+    hipLaunchKernelGGL((k_scan_down<true, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0));
 }
 
 // fill variants, selected at run time (KMX_FILL_VARIANT, see kmx_capi.hip)
