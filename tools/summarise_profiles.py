@@ -66,18 +66,24 @@ def main():
             "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024),
             "avg_launch_ms_kernel_trace": round(avg_ns[k][0] / 1e6, 4) if k in avg_ns else None,
         }
-    nq = bench["config"]["queries_per_gpu"]
-    red = max(fetch.get("kmx::k_scan_reduce", [0.0]))        # the nq-sized scan; smaller launches belong to the index build
+    # calibration of the gfx950 FETCH_SIZE correction in the same run: the largest k_scan_reduce launch reads exactly
+    # 4 bytes per item of a grid that is a whole number of 4096-item tiles (the histogram scan of the index build:
+    # 4^10 keys; before the search path lost its reduce launch, the 1e7-query scan)
+    red, red_items = 0.0, 0
+    with open(os.path.join(src, "fetch", "fetch_counter_collection.csv"), newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] == "FETCH_SIZE" and "k_scan_reduce" in row["Kernel_Name"] and float(row["Counter_Value"]) > red:
+                red, red_items = float(row["Counter_Value"]), int(row["Grid_Size"]) // 256 * 4096
     fill = next(k for k in kernels if k.startswith("kmx::k_fill<"))
     out = {
         "source": f"tools/profile_round.sh {a.tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
                   "--kernel-trace --stats, each over `python3 bench.py --no-cpu-baseline --no-open-compare --steps 8 --warmup 2`, MI355X",
         "units": "FETCH_SIZE / WRITE_SIZE are KiB as reported; fetch_bytes_corrected doubles FETCH_SIZE (gfx950 tallies 128-B "
-                 "requests at 64 B, MI355X_MICROARCH.md HBM section); calibration in the same run: the nq-sized k_scan_reduce "
-                 f"reads exactly 4*nq = {4 * nq} B",
+                 "requests at 64 B, MI355X_MICROARCH.md HBM section); calibration in the same run: the largest k_scan_reduce "
+                 f"launch reads exactly 4 B x {red_items} items = {4 * red_items} B",
         "bench_value_M_queries_per_s": bench["value"],
         "kernels": kernels,
-        "calibration_scan_reduce_fetch_ratio": round(red * 1024 / (4.0 * nq), 4),
+        "calibration_scan_reduce_fetch_ratio": round(red * 1024 / (4.0 * max(red_items, 1)), 4),
         "k_fill": {
             "kernel": fill,
             "hbm_bytes_per_launch": kernels[fill]["hbm_bytes_per_launch"],
