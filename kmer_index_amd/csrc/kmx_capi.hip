@@ -866,7 +866,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     const KmxIndexDev* dix = ix->d_index;
 
     HIP_TRY(hipMemsetAsync(ctr, 0, KMX_CTR_COUNT * sizeof(unsigned long long), s));
-    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>()); });
+    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), flags); });
     // speculative scan: already final when the batch holds no STITCH query
     // The downsweep also records the first query of every output tile (k_partition's job) when the
     // tile table kept from an earlier batch is large enough — the steady state.
@@ -931,8 +931,9 @@ static kmx_status search_finish(kmx_result* r)
         });
     };
     const uint64_t n_stitch_groups = r->h_ctr[KMX_CTR_STITCH], n_stitch_tiny = r->h_ctr[KMX_CTR_STITCH_TINY];   // front / back of stitch_list
-    r->n_stitch = n_stitch_groups + n_stitch_tiny;
-    r->last_had_stitch = r->n_stitch != 0;
+    const uint64_t n_stitch_pending = n_stitch_groups + n_stitch_tiny;                                  // still to be validated
+    r->n_stitch = n_stitch_pending + r->h_ctr[KMX_CTR_STITCH_RESOLVED];                                  // (k_lookup resolved the others itself)
+    r->last_had_stitch = n_stitch_pending != 0;
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
     r->n_prefix = n_prefix_small + n_prefix_big;
     r->n_error = r->h_ctr[KMX_CTR_ERROR];
@@ -942,7 +943,7 @@ static kmx_status search_finish(kmx_result* r)
     const uint64_t prefix_elems = r->h_ctr[KMX_CTR_PREFIX_ELEMS];
     const uint64_t max_runs = r->h_ctr[KMX_CTR_MAX_RUNS];
 
-    if (r->n_stitch) {
+    if (n_stitch_pending) {
         HIP_TRY(r->mask_words.ensure(r->n_mask_words * 8));
         // room for every candidate to survive (64 slots per mask word); without it k_compact decodes the masks
         static const bool no_survivors = getenv("KMX_NO_STITCH_HITS") != nullptr;
@@ -970,7 +971,7 @@ static kmx_status search_finish(kmx_result* r)
     HIP_TRY(r->tile_q.ensure((n_tiles + 1) * 4));
     uint32_t* out = r->out.as<uint32_t>();
     const uint64_t* hit_off = r->hit_off.as<uint64_t>();
-    const bool spec_ok = spec_fill && r->n_stitch == 0 && n_tiles <= spec_tiles;   // the early k_fill already did the work
+    const bool spec_ok = spec_fill && n_stitch_pending == 0 && n_tiles <= spec_tiles;   // the early k_fill already did the work
     if (!spec_ok) {
         if (n_tiles + 1 > tile_cap)   // first batch / the table had to grow: the scan could not fill it
             timed(ix, K_PARTITION, s, [&] { kmx::launch_partition(s, hit_off, nq, tile, n_tiles, r->tile_q.as<uint32_t>()); });
@@ -978,7 +979,7 @@ static kmx_status search_finish(kmx_result* r)
             kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, hit_off, r->tile_q.as<uint32_t>(), ctr + KMX_CTR_TOTAL_HITS, n_tiles, d, out);
         });
     }
-    if (r->n_stitch && !d.stitch_hits)
+    if (n_stitch_pending && !d.stitch_hits)
         timed(ix, K_COMPACT, s, [&] {
             if (n_stitch_groups) kmx::launch_compact(s, ix->d_arena, d, n_stitch_groups, r->mask_words.as<uint64_t>(), hit_off, out);
             if (n_stitch_tiny) {

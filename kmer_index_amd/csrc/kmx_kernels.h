@@ -25,7 +25,7 @@ struct QueryDesc {
 
 uint64_t lookup_blocks(uint64_t nq);
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
-                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits);
+                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits, uint32_t flags);
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);

@@ -200,7 +200,7 @@ __device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_stitch_tiny, n_prefix, n_prefix_big, n_error, n_none, n_more;
+    unsigned int n_stitch, n_stitch_tiny, n_resolved, n_prefix, n_prefix_big, n_error, n_none, n_more;
     unsigned long long words, pelems, hits;
     unsigned int max_runs;
     unsigned int base_stitch, base_stitch_tiny, base_prefix, base_prefix_big;
@@ -211,14 +211,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                                                       const uint8_t* __restrict__ qranks,
                                                       const uint64_t* __restrict__ qoff, uint64_t nq,
                                                       QueryDesc d, unsigned long long* __restrict__ ctr,
-                                                      uint64_t* __restrict__ block_hits)
+                                                      uint64_t* __restrict__ block_hits, uint32_t flags)
 {
     // block_hits[blockIdx.x] = sum of the block's hit counts: the first level of the scan that follows (k_scan_reduce's
     // job, for free here)
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_stitch_tiny = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
+        bc.n_stitch = bc.n_stitch_tiny = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = bc.hits = 0;
         bc.max_runs = 0;
     }
@@ -353,6 +353,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     uint32_t cnt = 0, c0 = 0;
     unsigned int my_stitch = 0, my_prefix = 0;
     unsigned long long my_words = 0;
+    bool resolved = false;        // a STITCH query whose few candidates were followed through every part right here
 
     if (q < nq) {
         const uint64_t b = qoff[q];
@@ -419,12 +420,42 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                     bool all = true;
                     Run first{0, 0}, extra{0, 0};
                     uint32_t extra_delta = 0;
+                    // Large k: the first part's bucket holds a handful of candidates.  They are followed through the
+                    // other parts while those are probed anyway (p + j*k must be in part j's bucket, :279-291); when
+                    // the survivors are one run of the bucket the query needs no validation pass, no mask words and
+                    // no second read-back: it is filled like an exact lookup.  Not with KEEP_MASKS (the words are the
+                    // point there).
+                    const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
+                    uint32_t cand[KMX_VRESOLVE];
+                    uint32_t alive = 0;
+                    bool track = false;
+                    auto follow = [&](const Run& r, uint32_t delta) {
+                        if (r.cnt > KMX_VTINY) { track = false; return; }
+                        uint32_t found = 0;
+                        for (uint32_t t = 0; t < r.cnt; ++t) {
+                            const uint32_t b = ar[r.src + t];
+#pragma unroll
+                            for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) found |= uint32_t(cand[i] + delta == b) << i;
+                        }
+                        alive &= found;
+                    };
                     for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
                         uint64_t h;
                         ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h, qend);
                         if (!ranks_ok) break;
                         Run r = probe(el, h);
-                        if (j == 0) first = r; else { extra = r; extra_delta = j * k; }
+                        if (j == 0) {
+                            first = r;
+                            track = !(flags & KMX_SEARCH_KEEP_MASKS) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
+                            if (track) {
+#pragma unroll
+                                for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) cand[i] = ar[r.src + (i < r.cnt ? i : 0u)];
+                                alive = (1u << r.cnt) - 1u;
+                            }
+                        } else {
+                            extra = r; extra_delta = j * k;
+                            if (track && r.cnt) follow(r, j * k);
+                        }
                         all = r.cnt != 0;
                     }
                     if (all && ranks_ok) {
@@ -437,11 +468,20 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                                 ranks_ok = rank_hash(qr + (m - k), k, sigma, h, qend);
                                 if (ranks_ok) { extra = probe(el, h); extra_delta = uint32_t(m - k); }
                                 all = ranks_ok && extra.cnt != 0;
+                                if (all && track) follow(extra, uint32_t(m - k));
                             }
                             if (all && ranks_ok) {
                                 kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
                                 key = extra.src;
                                 p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (P - 1 + (rest ? 1 : 0) > 1 ? KMX_P1_MORE : 0);
+                                if (track) {
+                                    const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
+                                    if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
+                                        resolved = true;
+                                        src = first.src + lo;
+                                        cnt = len;
+                                    }
+                                }
                             }
                         }
                     }
@@ -476,7 +516,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             }
             if (!ranks_ok) { status = KMX_Q_BAD_RANK; kind = KMX_KIND_NONE; cnt = 0; my_prefix = 0; }
         }
-        if (kind == KMX_KIND_STITCH) {
+        if (kind == KMX_KIND_STITCH && !resolved) {
             my_stitch = 1;
             my_words = uint64_t(c0) / 64 + 1;                 // compressed_bitset.hpp:23
         }
@@ -506,14 +546,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             }
         }
     }
+    if (resolved) atomicAdd(&bc.n_resolved, 1u);
     if (q < nq && status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
     if (q < nq && status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
-    kinds[it] = q < nq ? kind : uint8_t(KMX_KIND_NONE);
+    kinds[it] = (q < nq && !resolved) ? kind : uint8_t(KMX_KIND_NONE);    // (only the work-list bookkeeping below reads this)
     locs[it] = loc;
     locw[it] = loc_words;
     if (q < nq) {
         my_hits += cnt;
-        d.src[q] = kind == KMX_KIND_STITCH ? (src | SRC_SLOW) : (kind == KMX_KIND_PREFIX ? (src | SRC_FLAGS) : src);
+        d.src[q] = (kind == KMX_KIND_STITCH && !resolved) ? (src | SRC_SLOW) : (kind == KMX_KIND_PREFIX ? (src | SRC_FLAGS) : src);
         d.cnt[q] = cnt;
         d.kind[q] = kind;
         d.status[q] = status;
@@ -546,6 +587,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             if (bc.pelems) atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
             if (bc.max_runs) atomicMax(&ctr[KMX_CTR_MAX_RUNS], (unsigned long long)bc.max_runs);
         }
+        if (bc.n_resolved) atomicAdd(&ctr[KMX_CTR_STITCH_RESOLVED], (unsigned long long)bc.n_resolved);
         if (bc.n_error) atomicAdd(&ctr[KMX_CTR_ERROR], (unsigned long long)bc.n_error);
         if (bc.n_none) atomicAdd(&ctr[KMX_CTR_NONE], (unsigned long long)bc.n_none);
     }
@@ -1509,10 +1551,10 @@ static inline unsigned int blocks_for(uint64_t n, uint64_t per_block)
 uint64_t lookup_blocks(uint64_t nq) { return blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS); }
 
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
-                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits)
+                   uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits, uint32_t flags)
 {
     hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr,
-                       block_hits);
+                       block_hits, flags);
 }
 
 // The STITCH work list holds n_stitch queries from its front and n_tiny "tiny" ones from its back (list_end = one past

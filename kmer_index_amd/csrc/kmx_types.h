@@ -74,6 +74,7 @@ struct KmxIndexDev {
 
 // PREFIX queries whose slice has at most KMX_PSORT_MAX_RUNS per-key runs and KMX_PSORT_CAP positions are
 // sorted in LDS by one wave (k_prefix_sort_small); larger ones go through the global merge passes.
+#define KMX_VRESOLVE 4          // k_lookup follows up to this many candidates of a single-k query through its parts itself
 #define KMX_VTINY 8             // k_validate_tiny: one thread per STITCH query up to this many candidates / filter entries
 #define KMX_PSORT_MAX_RUNS 16
 #define KMX_PSORT_CAP 2048
@@ -96,5 +97,6 @@ enum {
     KMX_CTR_STITCH_MORE = 10, // STITCH queries with more further parts than the one QueryDesc::p1 names
     KMX_CTR_PREFIX_BIG = 11,  // PREFIX queries that are not 'small' (listed from the BACK of prefix_list)
     KMX_CTR_STITCH_TINY = 12, // STITCH queries with at most KMX_VTINY candidates and filter-bucket entries (listed from the BACK of stitch_list)
+    KMX_CTR_STITCH_RESOLVED = 13, // STITCH queries k_lookup resolved by itself (tiny first bucket, survivors one run of it)
     KMX_CTR_COUNT = 16
 };
