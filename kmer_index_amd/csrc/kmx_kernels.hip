@@ -367,6 +367,30 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         } else {
             const KmxPlanEntry pe = load_plan(ix, m);
             bool ranks_ok = true;
+            // Large k: the buckets hold a handful of positions.  Up to KMX_VRESOLVE start positions of the query are
+            // followed through the parts while those are probed anyway (p + offset_j must be in part j's bucket,
+            // :279-291, :541-551); when the survivors are one run of the first part's bucket the query needs no
+            // validation pass, no mask words and no second read-back: it is filled like an exact lookup.  Not with
+            // KEEP_MASKS (the words are the point there).
+            // Only for elements whose buckets average at most two positions: with longer buckets the extra loads cost more
+            // than the validation they save (BASELINE config 3: +0.16 ms of lookup for -0.05 ms of validation).
+            auto sparse_buckets = [](const KmxElemDev* e) {
+                return e->npos <= 2 * (e->table_kind == KMX_TABLE_DENSE ? e->n_keys : uint64_t(e->n_ukeys));
+            };
+            const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
+            uint32_t cand[KMX_VRESOLVE];
+            uint32_t alive = 0;
+            bool track = false;
+            auto follow = [&](const Run& r, uint32_t delta) {
+                if (r.cnt > KMX_VTINY) { track = false; return; }
+                uint32_t found = 0;
+                for (uint32_t t = 0; t < r.cnt; ++t) {
+                    const uint32_t b = ar[r.src + t];
+#pragma unroll
+                    for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) found |= uint32_t(cand[i] + delta == b) << i;
+                }
+                alive &= found;
+            };
             if (pe.scheme == KMX_SCHEME_SINGLE) {
                 const KmxElemDev* el = &elems_s[pe.elem];
                 const uint32_t k = el->k;
@@ -420,25 +444,6 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                     bool all = true;
                     Run first{0, 0}, extra{0, 0};
                     uint32_t extra_delta = 0;
-                    // Large k: the first part's bucket holds a handful of candidates.  They are followed through the
-                    // other parts while those are probed anyway (p + j*k must be in part j's bucket, :279-291); when
-                    // the survivors are one run of the bucket the query needs no validation pass, no mask words and
-                    // no second read-back: it is filled like an exact lookup.  Not with KEEP_MASKS (the words are the
-                    // point there).
-                    const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
-                    uint32_t cand[KMX_VRESOLVE];
-                    uint32_t alive = 0;
-                    bool track = false;
-                    auto follow = [&](const Run& r, uint32_t delta) {
-                        if (r.cnt > KMX_VTINY) { track = false; return; }
-                        uint32_t found = 0;
-                        for (uint32_t t = 0; t < r.cnt; ++t) {
-                            const uint32_t b = ar[r.src + t];
-#pragma unroll
-                            for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) found |= uint32_t(cand[i] + delta == b) << i;
-                        }
-                        alive &= found;
-                    };
                     for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
                         uint64_t h;
                         ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h, qend);
@@ -446,7 +451,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                         Run r = probe(el, h);
                         if (j == 0) {
                             first = r;
-                            track = !(flags & KMX_SEARCH_KEEP_MASKS) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
+                            track = !(flags & KMX_SEARCH_KEEP_MASKS) && sparse_buckets(el) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
                             if (track) {
 #pragma unroll
                                 for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) cand[i] = ar[r.src + (i < r.cnt ? i : 0u)];
@@ -502,7 +507,22 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                     ranks_ok = rank_hash(qr + mm, k, sigma, h, qend);
                     if (!ranks_ok) break;
                     r = probe(el, h);                         // search_k, :183-190 / :520
-                    if (j == 0) { extra = r; extra_delta = uint32_t(mm); }
+                    if (j == 0) {
+                        extra = r; extra_delta = uint32_t(mm);
+                        // the walk meets the LAST summand first: its bucket anchors the start positions p = a - offset
+                        track = !(flags & KMX_SEARCH_KEEP_MASKS) && nparts > 1 && sparse_buckets(el) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
+                        if (track) {
+                            alive = 0;
+#pragma unroll
+                            for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) {
+                                const uint32_t a = ar[r.src + (i < r.cnt ? i : 0u)];
+                                cand[i] = a - uint32_t(mm);
+                                alive |= uint32_t(i < r.cnt && a >= uint32_t(mm)) << i;
+                            }
+                        }
+                    } else if (track && r.cnt) {
+                        follow(r, uint32_t(mm));
+                    }
                     all = r.cnt != 0;                         // :521-524
                 }
                 if (all && ranks_ok) {
@@ -511,6 +531,21 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                         kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
                         key = extra.src;
                         p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (nparts > 2 ? KMX_P1_MORE : 0);
+                        if (track) {
+                            // r is the first summand's bucket now (offset 0): which of its entries are surviving starts?
+                            uint32_t fmask = 0;
+                            for (uint32_t t = 0; t < r.cnt; ++t) {
+                                const uint32_t b = ar[r.src + t];
+#pragma unroll
+                                for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) fmask |= uint32_t(((alive >> i) & 1u) && cand[i] == b) << t;
+                            }
+                            const uint32_t lo = fmask ? uint32_t(__ffs(int(fmask))) - 1u : 0u, len = uint32_t(__popc(fmask));
+                            if ((fmask >> lo) == (1u << len) - 1u) {           // one run of the bucket (or nothing)
+                                resolved = true;
+                                src = r.src + lo;
+                                cnt = len;
+                            }
+                        }
                     }
                 }
             }
