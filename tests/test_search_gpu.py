@@ -176,6 +176,46 @@ def test_largest_valid_k_of_an_alphabet(engine, orc, sigma, k):
             assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, q))
 
 
+@pytest.mark.parametrize("ks", [[20], [16, 24, 31], [9, 14]])
+def test_sparse_buckets_long_queries_resolved_in_lookup(engine, orc, ks):
+    """Large k: buckets of one to a few positions.  k_lookup follows the few start positions of such a query through
+    its parts itself (single-k: candidates of the first part; multi-k: anchors from the last summand) and marks the
+    query resolved when the survivors are one run of the first bucket; the others go to k_validate_tiny / k_validate.
+    Segments of the text are repeated (buckets of 2-4, survivors in the middle of a bucket, several survivors) and
+    queries end inside / outside the repeats.  Ground truth: the naive scan; with and without KEEP_MASKS."""
+    rng = np.random.default_rng(sum(ks))
+    text = rng.integers(0, 4, 300_000).astype(np.uint8)
+    for rep, (src0, dst0, ln) in enumerate([(1000, 50_000, 400), (1000, 120_000, 250), (1100, 200_000, 180), (70_000, 260_000, 90)]):
+        text[dst0:dst0 + ln] = text[src0:src0 + ln]
+    text[150_000:150_060] = 0                                   # a low-complexity stretch: longer buckets in the middle
+    idx = engine.Index(text, 4, ks)
+    qs = []
+    for m in (max(ks) + 1, 2 * min(ks), 48, 64, 100, 150, 200):
+        for s0 in (1000, 1050, 1100, 1190, 1300, 50_000, 50_100, 120_100, 200_050, 70_010, 260_020, 149_990, 5, 299_000 - m):
+            q = text[s0:s0 + m].copy()
+            qs.append(q)
+            if s0 % 100 == 0:
+                q2 = q.copy()
+                q2[m - 2] = (q2[m - 2] + 1) % 4                 # a mismatch near the end: every candidate fails late
+                qs.append(q2)
+    qranks, qoff = pack(qs)
+    o_off, o_pos, o_st, _ = orc.Index(text, 4, ks).search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=4)
+    n_multi_hit = 0
+    for flags in (engine.SEARCH_DEFAULT, engine.SEARCH_KEEP_MASKS, engine.SEARCH_COUNT_ONLY):
+        r = idx.search(qranks, qoff, flags=flags)
+        ho, pos, st, kd = r.host()
+        assert np.array_equal(st, o_st.astype(np.uint8)) and np.array_equal(ho, o_off), flags
+        if flags == engine.SEARCH_COUNT_ONLY:
+            continue
+        assert np.array_equal(pos, o_pos), flags
+        for i, q in enumerate(qs):
+            if st[i] == 0:
+                want = orc.naive_scan(text, q)
+                assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], want), (flags, i, len(q))
+                n_multi_hit += want.size > 1
+    assert n_multi_hit > 20                                      # the repeats really produce several occurrences
+
+
 def test_async_searches_rotate_over_two_results(engine, orc):
     """KMX_SEARCH_ASYNC: the call returns with the first half of the search enqueued; the next touch of the result
     completes it.  Two results in rotation over batches of every kind mix (the second halves — validation, sorts,
