@@ -1,0 +1,57 @@
+"""Paths that only run when a buffer cannot be had or a knob says so, exercised in a child process (the knobs are
+read once per process): without the survivor buffer k_validate<true> checks further parts in line and k_compact
+decodes the mask words (KMX_NO_STITCH_HITS); arenas beyond 4 GiB use 64-bit LDS records in k_fill (KMX_FORCE_REC64);
+no line-aligned copy (KMX_ALIGNED=0)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from kmer_index_amd import engine, synth
+from oracle import orc
+from tests.helpers import pack
+
+rng = np.random.default_rng(7)
+motif = rng.integers(0, 4, 53).astype(np.uint8)
+text = np.tile(motif, 4000)
+mut = rng.integers(0, text.size, text.size // 19)
+text[mut] = rng.integers(0, 4, mut.size)
+text = np.ascontiguousarray(text)
+for ks in ([7], [6, 9, 11], [16]):
+    idx = engine.Index(text, 4, ks)
+    oidx = orc.Index(text, 4, ks)
+    qs = []
+    for m in (5, 7, 9, 16, 18, 21, 28, 33, 45, 66, 100):
+        for s0 in (0, 13, 53 * 40 + 7, 53 * 2000 + 30, text.size - m):
+            qs.append(text[s0:s0 + m].copy())
+            qs.append(np.tile(motif, 3)[s0 %% 53:s0 %% 53 + m].copy())
+    qranks, qoff = pack(qs)
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, mode=orc.MODE_INTENDED, n_threads=4)
+    for flags in (engine.SEARCH_DEFAULT, engine.SEARCH_KEEP_MASKS):
+        res = engine.Result()
+        for rep in range(2):
+            ho, pos, st, kd = idx.search(qranks, qoff, flags=flags, result=res).host()
+            assert np.array_equal(st, o_st.astype(np.uint8)), (ks, flags, rep)
+            assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), (ks, flags, rep)
+    for i in range(0, len(qs), 5):
+        if o_st[i] == 0:
+            assert np.array_equal(o_pos[int(o_off[i]):int(o_off[i + 1])], orc.naive_scan(text, qs[i]))
+print("fallback child ok", int(o_off[-1]))
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env", [{"KMX_NO_STITCH_HITS": "1"}, {"KMX_FORCE_REC64": "1"}, {"KMX_ALIGNED": "0"},
+                                 {"KMX_NO_STITCH_HITS": "1", "KMX_FORCE_REC64": "1"}])
+def test_fallback_paths_in_a_child_process(env):
+    e = dict(os.environ)
+    e.update(env)
+    res = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=e)
+    assert res.returncode == 0 and "fallback child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
