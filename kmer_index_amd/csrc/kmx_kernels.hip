@@ -908,6 +908,103 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_tiny(const KmxIndexDev* 
     d.cnt[q] = valid;
 }
 
+// A long survivor list (a query inside a repeat of the text: thousands of candidates pass the filter) taken by the whole
+// wave: lane = survivor, two per lane, the parts one after the other — each lane computes the bucket of one part, the
+// wave then walks the 64 buckets, every lane binary-searching its survivors in lockstep — so that 128 searches are in
+// flight where a 16-lane group would run one survivor at a time.  Compaction in place, dropped survivors lose their
+// mask bit (several lanes may hit one word: atomic).
+#define KMX_VMORE_WAVE 48      // survivor lists longer than this go to the whole wave
+__device__ void validate_more_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
+                                   const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff, const QueryDesc& d,
+                                   uint32_t q, uint32_t tentative, uint64_t* __restrict__ mask_words)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t qb = qoff[q];
+    const uint64_t m = qoff[q + 1] - qb;
+    const uint8_t* __restrict__ qr = qranks + qb;
+    const uint8_t* __restrict__ qend = qranks + qoff[q + 1];
+    const uint32_t sigma = ix->sigma;
+    const KmxPlanEntry pe = load_plan(ix, m);
+    const bool single = pe.scheme == KMX_SCHEME_SINGLE;
+    const KmxElemDev* __restrict__ sel = single ? &ix->elems[pe.elem] : nullptr;
+    const uint32_t sk = single ? sel->k : 0u;
+    const uint32_t sP = single ? uint32_t(m / sk) : 0u;
+    const uint32_t n_extra = single ? sP - 1 + ((m % sk) ? 1u : 0u) : pe.nparts - 1u;
+    const uint64_t wbase = d.aux[q];
+    uint32_t* __restrict__ hits = d.stitch_hits + wbase * 64;
+    const uint64_t src = d.src[q] & ~SRC_FLAGS;
+    const uint32_t c0 = d.c0[q];
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < tentative; base += 2 * KMX_WAVE) {
+        const bool v0 = base + lane < tentative, v1 = base + KMX_WAVE + lane < tentative;
+        const uint32_t p0 = v0 ? hits[base + lane] : 0u, p1 = v1 ? hits[base + KMX_WAVE + lane] : 0u;
+        bool a0 = v0, a1 = v1;
+        for (uint32_t pb = 0; pb < n_extra && __any(a0 || a1); pb += KMX_WAVE) {
+            // lane = part pb + lane: its bucket and its offset in the query (as stitch_parts_hold)
+            const uint32_t e = pb + lane;
+            uint64_t rsrc = 0;
+            uint32_t rcnt = 0, rdl = 0;
+            if (e < n_extra) {
+                const KmxElemDev* __restrict__ el = sel;
+                uint32_t k = sk;
+                uint64_t start;
+                if (single) {
+                    start = (e < sP - 1) ? uint64_t(e + 1) * sk : (m - sk);
+                } else {
+                    uint64_t mm = m;
+                    for (uint32_t w = 0; w <= e; ++w) {
+                        const KmxPlanEntry en = load_plan(ix, mm);
+                        el = &ix->elems[en.elem];
+                        k = el->k;
+                        mm -= k;
+                    }
+                    start = mm;
+                }
+                uint64_t h;
+                rank_hash(qr + start, k, sigma, h, qend);
+                const Run r = probe(el, h);
+                rsrc = r.src; rcnt = r.cnt; rdl = uint32_t(start);
+            }
+            const uint32_t nb = min(uint32_t(KMX_WAVE), n_extra - pb);
+            for (uint32_t j = 0; j < nb && __any(a0 || a1); ++j) {
+                const uint64_t bs = __shfl(rsrc, int(j));
+                const uint32_t bn = uint32_t(__shfl(int(rcnt), int(j)));
+                const uint32_t dl = uint32_t(__shfl(int(rdl), int(j)));
+                const uint32_t* __restrict__ bk = arena + bs;
+                const uint32_t x0 = p0 + dl, x1 = p1 + dl;
+                uint32_t c0s = 0, c1s = 0;                                  // branch-free halving, both searches in lockstep
+                uint64_t P2 = 1;
+                while (P2 <= bn) P2 <<= 1;
+                for (uint32_t st = uint32_t(P2 >> 1); st; st >>= 1) {
+                    const uint32_t i0 = min(c0s + st - 1, bn ? bn - 1 : 0u), i1 = min(c1s + st - 1, bn ? bn - 1 : 0u);
+                    const uint32_t t0 = bk[i0], t1 = bk[i1];
+                    c0s += (c0s + st - 1 < bn && t0 < x0) ? st : 0u;
+                    c1s += (c1s + st - 1 < bn && t1 < x1) ? st : 0u;
+                }
+                a0 = a0 && c0s < bn && bk[min(c0s, bn ? bn - 1 : 0u)] == x0;   // binary_search :283, lower_bound :544-546
+                a1 = a1 && c1s < bn && bk[min(c1s, bn ? bn - 1 : 0u)] == x1;
+            }
+        }
+        // dropped survivors: their index among the candidates is their rank in the first part's bucket
+        if (v0 && !a0) {
+            const uint64_t idx = lower_bound_dev<uint32_t>(arena + src, c0, p0);
+            atomicAnd(reinterpret_cast<unsigned long long*>(mask_words + wbase + (idx >> 6)), ~(1ull << (idx & 63)));
+        }
+        if (v1 && !a1) {
+            const uint64_t idx = lower_bound_dev<uint32_t>(arena + src, c0, p1);
+            atomicAnd(reinterpret_cast<unsigned long long*>(mask_words + wbase + (idx >> 6)), ~(1ull << (idx & 63)));
+        }
+        // compaction in place: everything this round read lies at or behind `base`, everything it writes before base + 128
+        const uint64_t b0 = __ballot(a0), b1 = __ballot(a1);
+        if (a0) hits[kept + uint32_t(__popcll(b0 & below))] = p0;
+        kept += uint32_t(__popcll(b0));
+        if (a1) hits[kept + uint32_t(__popcll(b1 & below))] = p1;
+        kept += uint32_t(__popcll(b1));
+    }
+    if (lane == 0) d.cnt[q] = kept;
+}
+
 // k_validate_more — STITCH queries with further parts beyond the filter of k_validate<false>: every survivor
 // the filter left in stitch_hits is checked against all parts (one part per lane of the query's group);
 // the list is compacted in place, the mask bit of a dropped survivor is cleared and cnt is corrected.
@@ -927,7 +1024,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_more(const KmxIndexDev* 
         const uint32_t q = have ? d.stitch_list[i] : 0u;
         const uint64_t p1 = have ? d.p1[q] : 0;
         const uint32_t tentative = have ? d.cnt[q] : 0u;
-        const bool active = (p1 & KMX_P1_MORE) != 0 && tentative != 0;     // group-uniform
+        const bool more = (p1 & KMX_P1_MORE) != 0 && tentative != 0;       // group-uniform
+        const bool big = more && tentative > KMX_VMORE_WAVE;
+        // long survivor lists: one query at a time by the whole wave
+        for (uint32_t e = 0; e < KMX_VGROUPS; ++e) {
+            if (__shfl(int(big), int(e * KMX_VGROUP)))
+                validate_more_wave(ix, arena, qranks, qoff, d, uint32_t(__shfl(int(q), int(e * KMX_VGROUP))),
+                                   uint32_t(__shfl(int(tentative), int(e * KMX_VGROUP))), mask_words);
+        }
+        const bool active = more && !big;
         uint32_t rounds = active ? tentative : 0u;
 #pragma unroll
         for (int e = 1; e < KMX_VGROUPS; ++e) rounds = max(rounds, uint32_t(__shfl_xor(int(rounds), e * KMX_VGROUP)));
