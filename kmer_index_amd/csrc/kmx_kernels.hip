@@ -9,6 +9,7 @@
 //                   ballot + the compacted survivors
 //  [k_validate_more] queries with more parts: the survivors against every part, one part per lane
 //  [k_validate_tiny] STITCH queries with a handful of candidates (large k): one thread per query does all of it
+//  [k_validate_wave] long survivor lists and big queries (repeats of the text): one wave per query, smallest bucket as anchor
 //   k_scan_*        exclusive scan of the per-query hit counts -> hit_off
 //   k_partition     first query of every output tile
 //   k_fill          output-centric copy of bucket runs -> to_vector() lists
@@ -44,6 +45,10 @@ namespace kmx {
 #define SRC_PREFIX (uint64_t(1) << 62)
 #define SRC_FLAGS (SRC_SLOW | SRC_PREFIX)
 #define KMX_P1_MORE (uint64_t(1) << 63)    // QueryDesc::p1: the query has further parts beyond the one p1 names
+#define KMX_P1_BIG (uint64_t(1) << 62)     // the first part's bucket is long (a repeat of the text): k_validate leaves the
+                                           // query to validate_big_wave, which anchors it on its smallest bucket
+#define KMX_P1_DELTA_MASK 0x3FFFFFFFu      // offset of the filter part in the query (bits 32..61 of p1)
+#define KMX_VBIG 1024                      // candidates beyond which a STITCH query counts as big
 
 // ---------------------------------------------------------------------------
 // small device helpers
@@ -479,6 +484,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                                 kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
                                 key = extra.src;
                                 p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (P - 1 + (rest ? 1 : 0) > 1 ? KMX_P1_MORE : 0);
+                                if (!(flags & KMX_SEARCH_KEEP_MASKS) && first.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
                                 if (track) {
                                     const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
                                     if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
@@ -531,6 +537,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                         kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
                         key = extra.src;
                         p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (nparts > 2 ? KMX_P1_MORE : 0);
+                        if (!(flags & KMX_SEARCH_KEEP_MASKS) && r.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
                         if (track) {
                             // r is the first summand's bucket now (offset 0): which of its entries are surviving starts?
                             uint32_t fmask = 0;
@@ -564,7 +571,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         if (c0 <= KMX_VTINY && uint32_t(p1) <= KMX_VTINY) {
             loc = atomicAdd(&bc.n_stitch_tiny, 1u) | 0x80000000u;    // tiny: one thread validates it, listed from the back
         } else {
-            if (p1 & KMX_P1_MORE) atomicAdd(&bc.n_more, 1u);
+            if (p1 & (KMX_P1_MORE | KMX_P1_BIG)) atomicAdd(&bc.n_more, 1u);
             loc = atomicAdd(&bc.n_stitch, 1u);
         }
         loc_words = atomicAdd(&bc.words, my_words);
@@ -744,9 +751,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         const uint64_t wbase = have ? d.aux[q] : 0;
         uint64_t* __restrict__ words = mask_words + wbase;
         const uint64_t sbase = wbase * 64;
-        const bool fast = have;
+        const bool fast = have && (INLINE_MORE || !(p1 & KMX_P1_BIG));  // (big queries: validate_big_wave, from k_validate_more)
         const bool more = INLINE_MORE && (p1 & KMX_P1_MORE) != 0;
-        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & 0x7FFFFFFFu;
+        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
         const bool staged = fast && pcnt <= KMX_VSTAGE;
         // The staged bucket is padded with 0xFFFFFFFF (never a position) to the wave's largest power of
         // two, so that the search below is a fixed number of branch-free halving steps for all four groups.
@@ -885,7 +892,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_tiny(const KmxIndexDev* 
     const uint64_t src = d.src[q] & ~SRC_FLAGS;
     const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
     const bool more = (p1 & KMX_P1_MORE) != 0;
-    const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & 0x7FFFFFFFu;
+    const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
     uint32_t filt[KMX_VTINY];
 #pragma unroll
     for (uint32_t t = 0; t < KMX_VTINY; ++t) filt[t] = arena[t < pcnt ? p1src + t : p1src];      // straight-line loads
@@ -914,6 +921,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_tiny(const KmxIndexDev* 
 // flight where a 16-lane group would run one survivor at a time.  Compaction in place, dropped survivors lose their
 // mask bit (several lanes may hit one word: atomic).
 #define KMX_VMORE_WAVE 48      // survivor lists longer than this go to the whole wave
+#define KMX_VWAVE_SCAN 8       // k_validate_wave: list entries a wave looks at per round
 __device__ void validate_more_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
                                    const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff, const QueryDesc& d,
                                    uint32_t q, uint32_t tentative, uint64_t* __restrict__ mask_words)
@@ -1005,6 +1013,109 @@ __device__ void validate_more_wave(const KmxIndexDev* __restrict__ ix, const uin
     if (lane == 0) d.cnt[q] = kept;
 }
 
+// A STITCH query whose first part has a long bucket (KMX_P1_BIG: it starts inside a repeat of the text), by the whole
+// wave and without the filter stage: every part's bucket is looked up (lane = part), the SMALLEST one becomes the
+// anchor — a query that straddles the repeat is anchored outside it — and its entries a, as start positions p = a - offset,
+// are checked against all other parts, lane = candidate, two per lane, in lockstep.  The survivors go to stitch_hits
+// (ascending, as the anchor's bucket is) and the count to cnt; the mask words of such a query are not produced (nobody
+// reads them without KEEP_MASKS, and with it the query is not flagged).
+__device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
+                                  const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff, const QueryDesc& d,
+                                  uint32_t q)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t qb = qoff[q];
+    const uint64_t m = qoff[q + 1] - qb;
+    const uint8_t* __restrict__ qr = qranks + qb;
+    const uint8_t* __restrict__ qend = qranks + qoff[q + 1];
+    const uint32_t sigma = ix->sigma;
+    const KmxPlanEntry pe = load_plan(ix, m);
+    const bool single = pe.scheme == KMX_SCHEME_SINGLE;
+    const KmxElemDev* __restrict__ sel = single ? &ix->elems[pe.elem] : nullptr;
+    const uint32_t sk = single ? sel->k : 0u;
+    const uint32_t sP = single ? uint32_t(m / sk) : 0u;
+    const uint32_t n_further = single ? sP - 1 + ((m % sk) ? 1u : 0u) : pe.nparts - 1u;
+    const uint32_t n_all = n_further + 1;                              // index n_further: the first part (offset 0)
+    // bucket and offset of part e (as stitch_parts_hold; e == n_further: the first part)
+    auto part_of = [&](uint32_t e, uint64_t& rsrc, uint32_t& rcnt, uint32_t& rdl) {
+        rsrc = 0; rcnt = 0; rdl = 0;
+        if (e >= n_all) return;
+        const KmxElemDev* __restrict__ el = sel;
+        uint32_t k = sk;
+        uint64_t start;
+        if (single) {
+            start = e == n_further ? 0 : (e < sP - 1) ? uint64_t(e + 1) * sk : (m - sk);
+        } else {
+            uint64_t mm = m;
+            for (uint32_t w = 0; w <= e; ++w) {
+                const KmxPlanEntry en = load_plan(ix, mm);
+                el = &ix->elems[en.elem];
+                k = el->k;
+                mm -= k;
+            }
+            start = mm;
+        }
+        uint64_t h;
+        rank_hash(qr + start, k, sigma, h, qend);
+        const Run r = probe(el, h);
+        rsrc = r.src; rcnt = r.cnt; rdl = uint32_t(start);
+    };
+    // 1. the anchor: the part with the fewest positions
+    uint64_t a_src = 0;
+    uint32_t a_cnt = 0xFFFFFFFFu, a_dl = 0, a_e = 0;
+    for (uint32_t pb = 0; pb < n_all; pb += KMX_WAVE) {
+        uint64_t rsrc; uint32_t rcnt, rdl;
+        part_of(pb + lane, rsrc, rcnt, rdl);
+        uint64_t best = (uint64_t(pb + lane < n_all ? rcnt : 0xFFFFFFFFu) << 32) | (pb + lane);
+        for (int off = 32; off > 0; off >>= 1) best = min(best, uint64_t(__shfl_xor(best, off)));
+        if (uint32_t(best >> 32) < a_cnt) {
+            const int owner = int(uint32_t(best) - pb);
+            a_cnt = uint32_t(best >> 32); a_e = uint32_t(best);
+            a_src = __shfl(rsrc, owner); a_dl = uint32_t(__shfl(int(rdl), owner));
+        }
+    }
+    // 2. its entries against every other part
+    uint32_t* __restrict__ hits = d.stitch_hits + d.aux[q] * 64;
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    uint32_t kept = 0;
+    for (uint32_t base = 0; base < a_cnt; base += 2 * KMX_WAVE) {
+        const bool v0 = base + lane < a_cnt, v1 = base + KMX_WAVE + lane < a_cnt;
+        const uint32_t e0 = v0 ? arena[a_src + base + lane] : 0u, e1 = v1 ? arena[a_src + base + KMX_WAVE + lane] : 0u;
+        bool a0 = v0 && e0 >= a_dl, a1 = v1 && e1 >= a_dl;            // a start before the text is none
+        const uint32_t p0 = e0 - a_dl, p1 = e1 - a_dl;
+        for (uint32_t pb = 0; pb < n_all && __any(a0 || a1); pb += KMX_WAVE) {
+            uint64_t rsrc; uint32_t rcnt, rdl;
+            part_of(pb + lane, rsrc, rcnt, rdl);
+            const uint32_t nb = min(uint32_t(KMX_WAVE), n_all - pb);
+            for (uint32_t j = 0; j < nb && __any(a0 || a1); ++j) {
+                if (pb + j == a_e) continue;                            // the anchor itself
+                const uint64_t bs = __shfl(rsrc, int(j));
+                const uint32_t bn = uint32_t(__shfl(int(rcnt), int(j)));
+                const uint32_t dl = uint32_t(__shfl(int(rdl), int(j)));
+                const uint32_t* __restrict__ bk = arena + bs;
+                const uint32_t last = bn ? bn - 1 : 0u;
+                const uint32_t x0 = p0 + dl, x1 = p1 + dl;
+                uint32_t c0s = 0, c1s = 0;                              // branch-free halving, both searches in lockstep
+                uint64_t P2 = 1;
+                while (P2 <= bn) P2 <<= 1;
+                for (uint32_t st = uint32_t(P2 >> 1); st; st >>= 1) {
+                    const uint32_t t0 = bk[min(c0s + st - 1, last)], t1 = bk[min(c1s + st - 1, last)];
+                    c0s += (c0s + st - 1 < bn && t0 < x0) ? st : 0u;
+                    c1s += (c1s + st - 1 < bn && t1 < x1) ? st : 0u;
+                }
+                a0 = a0 && c0s < bn && bk[min(c0s, last)] == x0;       // binary_search :283, lower_bound :544-546
+                a1 = a1 && c1s < bn && bk[min(c1s, last)] == x1;
+            }
+        }
+        const uint64_t b0 = __ballot(a0), b1 = __ballot(a1);
+        if (a0) hits[kept + uint32_t(__popcll(b0 & below))] = p0;
+        kept += uint32_t(__popcll(b0));
+        if (a1) hits[kept + uint32_t(__popcll(b1 & below))] = p1;
+        kept += uint32_t(__popcll(b1));
+    }
+    if (lane == 0) d.cnt[q] = kept;
+}
+
 // k_validate_more — STITCH queries with further parts beyond the filter of k_validate<false>: every survivor
 // the filter left in stitch_hits is checked against all parts (one part per lane of the query's group);
 // the list is compacted in place, the mask bit of a dropped survivor is cleared and cnt is corrected.
@@ -1024,14 +1135,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_more(const KmxIndexDev* 
         const uint32_t q = have ? d.stitch_list[i] : 0u;
         const uint64_t p1 = have ? d.p1[q] : 0;
         const uint32_t tentative = have ? d.cnt[q] : 0u;
-        const bool more = (p1 & KMX_P1_MORE) != 0 && tentative != 0;       // group-uniform
+        // (big queries and long survivor lists: k_validate_wave)
+        const bool more = !(p1 & KMX_P1_BIG) && (p1 & KMX_P1_MORE) != 0 && tentative != 0;   // group-uniform
         const bool big = more && tentative > KMX_VMORE_WAVE;
-        // long survivor lists: one query at a time by the whole wave
-        for (uint32_t e = 0; e < KMX_VGROUPS; ++e) {
-            if (__shfl(int(big), int(e * KMX_VGROUP)))
-                validate_more_wave(ix, arena, qranks, qoff, d, uint32_t(__shfl(int(q), int(e * KMX_VGROUP))),
-                                   uint32_t(__shfl(int(tentative), int(e * KMX_VGROUP))), mask_words);
-        }
         const bool active = more && !big;
         uint32_t rounds = active ? tentative : 0u;
 #pragma unroll
@@ -1058,6 +1164,39 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_more(const KmxIndexDev* 
             }
         }
         if (active && gl == 0) d.cnt[q] = kept;
+    }
+}
+
+// k_validate_wave — the STITCH queries that want a whole wave: big ones (validate_big_wave) and those whose filter left
+// a long survivor list (validate_more_wave).  Lane = list entry while looking for them, then the wave takes the flagged
+// queries one by one.  A kernel of its own so that the registers of the wave-wide paths do not cost the group paths of
+// k_validate_more their occupancy.
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate_wave(const KmxIndexDev* __restrict__ ix,
+                                                             const uint32_t* __restrict__ arena,
+                                                             const uint8_t* __restrict__ qranks,
+                                                             const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                             uint64_t n_stitch, uint64_t* __restrict__ mask_words)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    // KMX_VWAVE_SCAN list entries per wave and round: few enough that the flagged queries spread over many waves
+    for (uint64_t i0 = wave * KMX_VWAVE_SCAN; i0 < n_stitch; i0 += n_waves * KMX_VWAVE_SCAN) {
+        const uint64_t i = i0 + lane;
+        const bool have = lane < KMX_VWAVE_SCAN && i < n_stitch;
+        const uint32_t q = have ? d.stitch_list[i] : 0u;
+        const uint64_t p1 = have ? d.p1[q] : 0;
+        const uint32_t tentative = have ? d.cnt[q] : 0u;
+        const bool whole = (p1 & KMX_P1_BIG) != 0;
+        const bool longlist = !whole && (p1 & KMX_P1_MORE) != 0 && tentative > KMX_VMORE_WAVE;
+        uint64_t todo = __ballot(whole || longlist);
+        while (todo) {
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            const uint32_t ql = uint32_t(__shfl(int(q), l));
+            if (__shfl(int(whole), l)) validate_big_wave(ix, arena, qranks, qoff, d, ql);
+            else validate_more_wave(ix, arena, qranks, qoff, d, ql, uint32_t(__shfl(int(tentative), l)), mask_words);
+        }
     }
 }
 
@@ -1716,7 +1855,12 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
         return;
     }
     hipLaunchKernelGGL(k_validate<false>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
-    if (n_more) hipLaunchKernelGGL(k_validate_more, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
+    if (n_more) {
+        hipLaunchKernelGGL(k_validate_more, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
+        const uint64_t wwaves = (n_stitch + KMX_VWAVE_SCAN - 1) / KMX_VWAVE_SCAN;
+        const unsigned int wblocks = (unsigned int)std::min<uint64_t>((wwaves + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(k_validate_wave, dim3(wblocks ? wblocks : 1), block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
+    }
 }
 
 uint64_t scan_blocks(uint64_t n) { return blocks_for(n, KMX_SCAN_TILE); }
