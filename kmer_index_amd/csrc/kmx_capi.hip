@@ -409,6 +409,26 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
             if ((st = upload(ix, im.slots.data(), im.slots.size(), &el.slots)) != KMX_OK) return bail(st);
             if ((st = upload(ix, im.ukeys.data(), im.ukeys.size(), &el.ukeys)) != KMX_OK) return bail(st);
         }
+        el.dir = nullptr; el.dir_shift = 0; el.n_dir = 0;
+        if (im.table_kind == KMX_TABLE_OPEN && el.n_ukeys >= 1024) {
+            // directory over the sorted keys: 2^D cells of about 16 keys (at most 2^20 cells = 4 MB)
+            uint32_t key_bits = 1;
+            while (key_bits < 64 && (im.n_keys - 1) >> key_bits) ++key_bits;
+            uint32_t lg = 0;
+            while ((uint64_t(1) << lg) < el.n_ukeys) ++lg;
+            const uint32_t D = std::min<uint32_t>(std::min<uint32_t>(20, key_bits), lg > 8 ? lg - 4 : 4);
+            void* p = nullptr;
+            if (hipMalloc(&p, ((size_t(1) << D) + 1) * 4 + 64) == hipSuccess) {
+                ix->allocs.push_back(p);
+                ix->device_bytes += ((size_t(1) << D) + 1) * 4;
+                el.dir = static_cast<const uint32_t*>(p);
+                el.dir_shift = key_bits - D;
+                el.n_dir = 1u << D;
+                kmx::launch_build_dir(nullptr, el.ukeys, el.n_ukeys, el.dir_shift, el.n_dir, static_cast<uint32_t*>(p));
+            } else {
+                (void)hipGetLastError();                            // no directory: the searches run over the whole key array
+            }
+        }
         base += im.region;
         im = kmx::ElemImage();   // release host memory early
     }

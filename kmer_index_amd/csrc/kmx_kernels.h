@@ -29,6 +29,7 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);
+void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, uint32_t shift, uint32_t n_dir, uint32_t* d_dir);
 
 // kmx_build_sort.hip — device construction of an element with a key space beyond the histogram path:
 // positions (grouped by hash, ascending inside a group) into d_positions[n - k + 1], tables into new allocations

@@ -419,8 +419,16 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
                             if (el->table_kind == KMX_TABLE_DENSE) {
                                 klo = hp; khi = hp + R;
                             } else {
-                                klo = lower_bound_dev<uint64_t>(as_global(el->ukeys), el->n_ukeys, hp);
-                                khi = lower_bound_dev<uint64_t>(as_global(el->ukeys), el->n_ukeys, hp + R);
+                                const KMX_GLOBAL uint64_t* uk = as_global(el->ukeys);
+                                auto first_key_at_least = [&](uint64_t v) -> uint64_t {
+                                    if (!el->dir) return lower_bound_dev<uint64_t>(uk, el->n_ukeys, v);
+                                    const uint64_t j = v >> el->dir_shift;              // the directory cell of v
+                                    if (j >= el->n_dir) return el->n_ukeys;
+                                    const uint32_t c_lo = as_global(el->dir)[j], c_hi = as_global(el->dir)[j + 1];
+                                    return c_lo + lower_bound_dev<uint64_t>(uk + c_lo, c_hi - c_lo, v);
+                                };
+                                klo = first_key_at_least(hp);
+                                khi = first_key_at_least(hp + R);
                             }
                             const uint32_t lo = as_global(el->offs)[klo], hi = as_global(el->offs)[khi];
                             // check_last_kmer, :90-112: offsets n-k+i, i in [1, k-m], where no k-mer
@@ -2198,6 +2206,20 @@ void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint3
         if (d_atab)
             hipLaunchKernelGGL(k_build_atab, dim3(blocks_for(n_keys + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_offs, d_aoffs, n_keys, region_end, d_atab);
     }
+}
+
+// directory over the sorted distinct keys of an open table: dir[j] = first index with ukeys[index] >= j << shift
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_dir(const uint64_t* __restrict__ ukeys, uint64_t n_ukeys, uint32_t shift,
+                                                         uint32_t n_dir, uint32_t* __restrict__ dir)
+{
+    const uint64_t j = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (j > n_dir) return;
+    dir[j] = j == n_dir ? uint32_t(n_ukeys) : uint32_t(lower_bound_dev<uint64_t>(ukeys, n_ukeys, j << shift));
+}
+
+void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, uint32_t shift, uint32_t n_dir, uint32_t* d_dir)
+{
+    hipLaunchKernelGGL(k_build_dir, dim3(blocks_for(uint64_t(n_dir) + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_ukeys, n_ukeys, shift, n_dir, d_dir);
 }
 
 // second stage for buckets beyond the wave sort's capacity (call when max bucket > KMX_PSORT_CAP)

@@ -42,6 +42,11 @@ struct KmxElemDev {
                            // those bits, so an exact lookup reads 8 bytes of ONE 4-byte-per-key table.  Open tables
                            // carry the aligned start in KmxSlot::off instead.  NULL: no aligned copy.
     uint64_t region;       // elements this element occupies in the arena (contiguous copy [+ aligned copy])
+    const uint32_t* dir;   // open only (NULL: none): dir[j] = index of the first distinct key >= j << dir_shift, n_dir + 1
+                           // entries — narrows the two binary searches of a prefix range from the whole key array to one
+                           // directory cell.  Derived from ukeys when the index is installed; not part of the image.
+    uint32_t dir_shift;
+    uint32_t n_dir;
 };
 
 // Planner entry for one query length m — what kmer_index::search consults at
