@@ -4,25 +4,43 @@
 One "step" = one pass of the hot path over one batch: 1e7 uniform random DNA4 10-mers per GPU against a
 k=10 index of a 1e8-bp synthetic text (BASELINE.json configs[1]); inputs resident in HBM before the timed
 region; the index is replicated per GPU and every rank searches its own query shard (weak scaling, no
-data-path collective; per-rank totals are exchanged once after the timed region).
+data-path collective in the `value` leg; per-rank totals are exchanged once after the timed region).
+
+Launch forms (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI):
+  python bench.py --gpus N ...                              this process only SPAWNS the N ranks (it never touches a
+                                                            GPU), waits for them and exits with their status;
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+                                                            the launcher already made the ranks (RANK / LOCAL_RANK /
+                                                            WORLD_SIZE / MASTER_* in the environment).
+Fewer than N visible devices is an error (exit code 3), never a silent 1-GPU run.
+
+At N > 1 the same JSON line also carries `gather_hits`: the same K steps with the RCCL gatherv of every hit list to
+rank 0 inside each step (grouped point-to-point exchange, gather of step i under the search of step i+1).
 
 Prints ONE JSON line on rank 0 (see the bench contract in the task / DESIGN.md §6).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+XGMI_LINK_GBPS = 153.0   # per direct link and direction (SURVEY §5 / MI355X_MICROARCH.md)
+
+# (sigma, n, ks, queries per GPU, query lengths, planted share, text seed, query seed)
+CFG = {2: (4, 100_000_000, [10], 10_000_000, [10], 0.0, 1002, 2002),
+       3: (4, 100_000_000, [8, 10, 12], 10_000_000, [8, 10, 12, 20, 22, 24], 0.5, 1003, 2003),
+       4: (5, 100_000_000, [10], 12_500_000, [10], 0.0, 1004, 2004),
+       5: (20, 10_000_000, [5], 10_000_000, [5], 0.5, 1005, 2005)}
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -35,11 +53,10 @@ def main():
                     help="auto = the engine's default policy (direct addressing when sigma^k <= 4(n-k+1), else open addressing)")
     ap.add_argument("--no-open-compare", action="store_true",
                     help="skip the extra leg that times the same workload on the open-addressing table (N=1, config 2 only)")
-    ap.add_argument("--gather", choices=["totals", "hits"], default="totals",
-                    help="totals: hit lists stay sharded where they were produced, per-shard totals exchanged after the timed region "
-                         "(default, zero data-path collective); hits: RCCL gatherv of every hit list to rank 0 inside each step")
-    ap.add_argument("--streams", type=int, default=1,
-                    help="HIP streams (and result handles) the steps alternate over; >1 lets step i+1's lookup/scan overlap step i's fill")
+    ap.add_argument("--gather", choices=["both", "totals", "hits"], default="both",
+                    help="both (default): `value` from the sharded leg (hit lists stay where they were produced, per-shard totals "
+                         "exchanged after the timed region) and, at N > 1, a second leg with the RCCL gatherv of every hit list to rank 0 "
+                         "inside each step, reported as gather_hits; totals: first leg only; hits: `value` IS the gather leg")
     ap.add_argument("--pipeline", type=int, default=2,
                     help="result handles the steps rotate over on ONE stream with KMX_SEARCH_ASYNC: the host enqueues step i+1 while "
                          "step i runs and reads step i's counters when its handle comes round again (1 = every step waits for its own)")
@@ -47,8 +64,70 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
     ap.add_argument("--verify", type=int, default=20000, help="queries checked against the oracle after timing")
-    args = ap.parse_args()
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="rehearsal only: allow more ranks than visible GPUs (ranks share devices; the exchange runs over gloo because "
+                         "RCCL refuses two ranks on one device).  The JSON line says so.")
+    return ap.parse_args(argv)
 
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launcher(args, argv):
+    """`python bench.py --gpus N` without a distributed launcher: spawn the N ranks.  This process never initialises a
+    GPU (torch.cuda.device_count() does not on this image), so the children start from a clean parent."""
+    import torch
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus and not args.oversubscribe:
+        print(f"[bench] --gpus {args.gpus} but only {n_dev} GPU(s) visible: refusing to report a smaller run as N={args.gpus}",
+              file=sys.stderr, flush=True)
+        return 3
+    env = dict(os.environ)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("MASTER_PORT", str(_free_port()))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["WORLD_SIZE"] = env["LOCAL_WORLD_SIZE"] = str(args.gpus)
+    procs = []
+    for r in range(args.gpus):
+        e = dict(env)
+        e["RANK"] = e["LOCAL_RANK"] = str(r)
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for o in pending:               # a failed rank leaves the others stuck in a collective
+                        o.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    if "RANK" not in os.environ and "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launcher(args, argv))
+    sys.exit(worker(args))
+
+
+def worker(args):
+    import numpy as np
     import torch
     import torch.distributed as dist
     from kmer_index_amd import dist as kdist
@@ -57,33 +136,39 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the engine has no CPU path")
-    n_dev = torch.cuda.device_count()
-    dev_index = local_rank % max(n_dev, 1)          # (== local_rank on a real N-GPU node)
-    torch.cuda.set_device(dev_index)
-    dev = torch.device("cuda", dev_index)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("KMX_DIST_BACKEND", "nccl")   # "gloo" only to rehearse N ranks on one GPU
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
 
     def log(*a):
         if rank == 0:
             print("[bench]", *a, file=sys.stderr, flush=True)
 
-    # (sigma, n, ks, queries per GPU, query lengths, planted share, text seed, query seed)
-    CFG = {2: (4, 100_000_000, [10], 10_000_000, [10], 0.0, 1002, 2002),
-           3: (4, 100_000_000, [8, 10, 12], 10_000_000, [8, 10, 12, 20, 22, 24], 0.5, 1003, 2003),
-           4: (5, 100_000_000, [10], 12_500_000, [10], 0.0, 1004, 2004),
-           5: (20, 10_000_000, [5], 10_000_000, [5], 0.5, 1005, 2005)}
+    if world != args.gpus:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU", file=sys.stderr, flush=True)
+        return 3
+    n_dev = torch.cuda.device_count()
+    if n_dev == 0 or not torch.cuda.is_available():
+        print("[bench] bench.py needs a GPU: the engine has no CPU path", file=sys.stderr, flush=True)
+        return 3
+    if n_dev < local_world and not args.oversubscribe:
+        print(f"[bench] {local_world} local ranks but only {n_dev} GPU(s) visible: refusing (use --oversubscribe to rehearse)",
+              file=sys.stderr, flush=True)
+        return 3
+    dev_index = local_rank % n_dev                   # == local_rank unless oversubscribed
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    backend = None
+    if world > 1 or os.environ.get("KMX_BENCH_INIT_PG"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        backend = "gloo" if (args.oversubscribe and n_dev < local_world) else os.environ.get("KMX_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    comm_dev = dev if backend == "nccl" else None    # where collectives' tensors live
+
     sigma, n_cfg, ks, nq_cfg, qlens, planted, tseed, qseed = CFG[args.config]
-    args.sigma, args.k = sigma, ks[0] if len(ks) == 1 else 0
+    args.sigma = sigma
     args.n = args.n or n_cfg
     args.nq = args.nq or nq_cfg
     t0 = time.time()
@@ -95,7 +180,7 @@ def main():
     info = idx.info()
     log(f"index built+uploaded in {time.time() - t0:.1f}s: {info}")
 
-    # this rank's query shard: letters [rank*nq*m, (rank+1)*nq*m) of query stream 2002
+    # this rank's query shard: letters [rank*nq*m, (rank+1)*nq*m) of the config's query stream
     nq = args.nq
     if planted == 0.0:
         m = qlens[0]
@@ -114,77 +199,174 @@ def main():
     d_qoff = torch.from_numpy(qoff_host.view(np.int64)).to(dev)
     torch.cuda.synchronize()
 
-    n_streams = max(1, args.streams)
-    depth = max(1, args.pipeline) if n_streams == 1 else 1
-    t_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(n_streams - 1)]
-    results = [engine.Result() for _ in range(max(n_streams, depth))]
+    depth = max(1, args.pipeline)
+    main_stream = torch.cuda.current_stream()
+
+    def barrier():
+        if backend is not None and world > 1:
+            dist.barrier()
+
+    # ------------------------------------------------------------------------------------------------------------
+    # leg 1 — sharded: hit lists stay in the HBM of the GPU that produced them.  `depth` result handles rotate on one
+    # stream with KMX_SEARCH_ASYNC (the host enqueues step i+1 while step i runs).
+    # ------------------------------------------------------------------------------------------------------------
+    def run_sharded(index, steps, warmup, collect_stats):
+        results = [engine.Result() for _ in range(depth)]
+        flags = engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT
+        no = [0]
+
+        def step():
+            r_ = results[no[0] % depth]
+            no[0] += 1
+            index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=flags, stream=main_stream.cuda_stream, result=r_)
+
+        # setup, like the index build: every result handle allocates its device buffers (grow-only, sized by its first
+        # batch) before the W warmup steps, so that neither warmup nor the timed region holds an allocation
+        for r_ in results:
+            for _ in range(2):
+                index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=main_stream.cuda_stream, result=r_)
+        torch.cuda.synchronize()
+        for _ in range(warmup):
+            step()
+        for r_ in results:
+            r_.counts()                                   # no warmup step is left pending into the timed region
+        torch.cuda.synchronize()
+        if collect_stats:
+            index.stats_enable(True)
+            index.stats_reset()
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        for r_ in results:
+            r_.counts()                                   # completes a step that is still pending on its handle (inside the timed region)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        stats = None
+        if collect_stats:
+            stats = index.stats()
+            index.stats_enable(False)
+        return elapsed, results, stats
+
+    # ------------------------------------------------------------------------------------------------------------
+    # leg 2 — gather: every step ends with all hit lists on rank 0.  Two handles on two compute streams; the gather of
+    # step i runs on a third stream (and on RCCL's own) while step i+1 searches; a handle is searched into again only
+    # after its gather has drained it.
+    # ------------------------------------------------------------------------------------------------------------
+    def run_gather(index, steps, warmup):
+        streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        comm = torch.cuda.Stream(device=dev)
+        results = [engine.Result() for _ in range(2)]
+        drained = [None, None]                            # event: the gather that read this handle is complete
+        gat = kdist.HitGather(dst=0)
+        g_events = []                                     # (start, end) pairs around every timed gather on `comm`
+        timing = [False]
+        for h in range(2):
+            for _ in range(2):
+                index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=streams[h].cuda_stream, result=results[h])
+        torch.cuda.synchronize()
+
+        def enqueue(i):
+            h = i % 2
+            if drained[h] is not None:
+                streams[h].wait_event(drained[h])
+            index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=engine.SEARCH_ASYNC, stream=streams[h].cuda_stream, result=results[h])
+
+        def complete(i):
+            h = i % 2
+            c = results[h].counts()                       # host waits for step i's counters; launches whatever the first half left
+            t_off, t_pos = results[h].device_tensors(dev)
+            ready = torch.cuda.Event()
+            ready.record(streams[h])
+            with torch.cuda.stream(comm):
+                comm.wait_event(ready)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if timing[0] else None
+                if ev:
+                    ev[0].record(comm)
+                if backend == "nccl":
+                    gat.gather(t_off, t_pos)
+                else:                                     # gloo rehearsal: the exchange goes through host memory
+                    comm.synchronize()
+                    gat.gather(t_off.cpu(), t_pos.cpu())
+                if ev:
+                    ev[1].record(comm)
+                    g_events.append(ev)
+                drained[h] = torch.cuda.Event()
+                drained[h].record(comm)
+            return c
+
+        def run(k):
+            enqueue(0)
+            for i in range(1, k):
+                enqueue(i)
+                complete(i - 1)
+            c = complete(k - 1)
+            comm.synchronize()
+            return c
+
+        run(max(warmup, 2))
+        torch.cuda.synchronize()
+        barrier()
+        torch.cuda.synchronize()
+        timing[0] = True
+        t0 = time.perf_counter()
+        c = run(steps)
+        torch.cuda.synchronize()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        g_ms = [a.elapsed_time(b) for a, b in g_events]
+        out = {"elapsed": elapsed, "gather_ms": sum(g_ms) / max(len(g_ms), 1), "bytes_per_peer": list(gat.last_bytes_per_peer),
+               "n_hits": c["n_hits"]}
+        if rank == 0 and gat.g_off is not None:
+            nq_total = nq * world
+            out["gathered_queries"] = nq_total
+            out["gathered_hits"] = int(gat.g_off[nq_total].item())
+        for r_ in results:
+            r_.close()
+        return out
+
+    # (KMX_BENCH_INIT_PG: a 1-rank process group, so that a 1-GPU box still drives the RCCL code path end to end)
+    want_gather = backend is not None and args.gather in ("both", "hits")
+    elapsed, results, stats = run_sharded(idx, args.steps, args.warmup, True)
     res = results[0]
-    step_no = [0]
-    step_flags = engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT
-
-    def step():
-        i = step_no[0] % len(results)
-        step_no[0] += 1
-        idx.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=step_flags, stream=t_streams[i % n_streams].cuda_stream, result=results[i])
-        if world > 1 and args.gather == "hits":
-            with torch.cuda.stream(t_streams[i]):
-                t_off, t_pos = results[i].device_tensors(dev)
-                kdist.gather_hit_lists(t_off, t_pos, dst=0)
-
-    # setup, like the index build: every result handle allocates its device buffers (grow-only, sized by its first
-    # batch) before the W warmup steps, so that neither warmup nor the timed region holds an allocation
-    for r_ in results:
-        for _ in range(2):
-            idx.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=t_streams[0].cuda_stream, result=r_)
-    torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        step()
-    for r_ in results:
-        r_.counts()                                   # no warmup step is left pending into the timed region
-    torch.cuda.synchronize()
-    idx.stats_enable(True)
-    idx.stats_reset()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    for r_ in results:
-        r_.counts()                                   # completes a step that is still pending on its handle (inside the timed region)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    stats = idx.stats()
-    idx.stats_enable(False)
     counts = res.counts()
+    gather_leg = run_gather(idx, args.steps, args.warmup) if want_gather else None
 
-    t_el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t_el = torch.tensor([elapsed, gather_leg["elapsed"] if gather_leg else 0.0], dtype=torch.float64, device=comm_dev)
     total_hits = counts["n_hits"]
-    if world > 1:
-        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)
-        totals = kdist.all_gather_totals(nq, counts["n_hits"], device=dev)    # the one exchange: per-shard totals
+    fill = stats.get("k_fill", {"launches": 0, "total_ms": 0.0})
+    fill_ms = fill["total_ms"] / max(fill["launches"], 1)
+    per_rank = None
+    rccl = None
+    if backend is not None:
+        dist.all_reduce(t_el, op=dist.ReduceOp.MAX)                    # max over ranks (the contract's clock)
+        totals = kdist.all_gather_totals(nq, counts["n_hits"], device=comm_dev)    # the one exchange: per-shard totals
         total_hits = int(totals[:, 1].sum())
-    elapsed = float(t_el.item())
+        mine = torch.tensor([fill_ms, float(counts["n_hits"]), float(elapsed)], dtype=torch.float64, device=comm_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
+        chk = torch.tensor([rank + 1], dtype=torch.int64, device=comm_dev)
+        dist.all_reduce(chk)
+        rccl = {"backend": backend + (" (RCCL)" if backend == "nccl" else " (rehearsal: ranks share a device)"),
+                "ranks_seen": int(dist.get_world_size()), "all_reduce_ok": int(chk.item()) == world * (world + 1) // 2,
+                "devices_visible": n_dev}
+    elapsed = float(t_el[0].item())
+    if gather_leg:
+        gather_leg["elapsed"] = float(t_el[1].item())
 
-    # ---- the literal north_star variant (open-addressing probe) on the same workload, outside the timed region ----
+    # ---- the literal north_star variant (open-addressing probe) on the same workload and the same pipeline, outside the timed region ----
     open_leg = None
     if world == 1 and args.config == 2 and not args.no_open_compare and info["tables"] != [engine.TABLE_OPEN] * len(ks):
         idx_o = engine.Index(text, args.sigma, ks, table=engine.TABLE_OPEN, device=dev_index)
-        res_o = engine.Result()
-        for _ in range(args.warmup):
-            idx_o.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=t_streams[0].cuda_stream, result=res_o)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            idx_o.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=t_streams[0].cuda_stream, result=res_o)
-        torch.cuda.synchronize()
-        dt_o = time.perf_counter() - t1
-        same = res_o.counts()["n_hits"] == counts["n_hits"]
+        dt_o, res_o, _ = run_sharded(idx_o, args.steps, args.warmup, False)
+        same = res_o[0].counts()["n_hits"] == counts["n_hits"]
         open_leg = {"value": round(nq * args.steps / dt_o / 1e6, 3), "unit": "M queries/s", "ms_per_step": round(dt_o / args.steps * 1e3, 4),
-                    "table": "open addressing, 16-B slots, load <= 0.5", "same_hit_total": bool(same)}
-        res_o.close()
+                    "table": "open addressing, 16-B slots, load <= 0.5", "pipeline_depth": depth, "same_hit_total": bool(same)}
+        for r_ in res_o:
+            r_.close()
         idx_o.close()
 
     # ---- verification of a sample against the CPU oracle (after the timed region) ----
@@ -234,6 +416,8 @@ def main():
                 sel = lens[qi] > j
                 ok &= bool(np.array_equal(text[pos[sel] + j], qr_host[qoff_host[qi[sel]].astype(np.int64) + j]))
             verified = bool(ok)
+        if gather_leg:                                            # the gathered arrays must account for every shard
+            verified = verified and gather_leg.get("gathered_hits") == total_hits
         if not verified:
             log("VERIFICATION FAILED")
 
@@ -241,23 +425,50 @@ def main():
         n_total_q = nq * world
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total_q * args.steps / elapsed / 1e6
-        fill = stats.get("k_fill", {"launches": 0, "total_ms": 0.0})
-        fill_ms = fill["total_ms"] / max(fill["launches"], 1)
         n_hits_rank = counts["n_hits"]
         # algorithmic bytes: per query R = m + 16 + 4c, W = 8 + 4c.  k_fill moves the 4c + 4c part.
         fill_bytes = 8.0 * n_hits_rank
-        job_bytes = float(n_letters) + float(nq) * (16 + 8) + 8.0 * n_hits_rank
+        read_bytes = float(n_letters) + 16.0 * nq + 4.0 * n_hits_rank
+        job_bytes = read_bytes + 8.0 * nq + 4.0 * n_hits_rank
         achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
         kernels_ms = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items() if v["launches"]}
         # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 --pmc
         # FETCH_SIZE / WRITE_SIZE in separate passes, gfx950 x2 read correction) — only when the workload matches it.
         traffic, traffic_src = None, None
-        try:
-            prof = json.load(open(os.path.join(ROOT, "profiles", "pmc_summary_current.json")))
-            if prof["k_fill"]["algorithmic_bytes_per_launch"] == int(fill_bytes):
-                traffic, traffic_src = prof["k_fill"]["hbm_bytes_per_launch"], "profiles/pmc_summary_current.json"
-        except Exception:
-            pass
+        for name in ("pmc_summary_current.json", f"pmc_summary_current_cfg{args.config}.json"):
+            try:
+                prof = json.load(open(os.path.join(ROOT, "profiles", name)))
+                if prof["k_fill"]["algorithmic_bytes_per_launch"] == int(fill_bytes):
+                    traffic, traffic_src = prof["k_fill"]["hbm_bytes_per_launch"], "profiles/" + name
+                    break
+            except Exception:
+                pass
+        roofline = {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),
+                    "job_algorithmic_GBps": round(job_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                    "job_frac": round(job_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                    # north_star's wording is the READ roofline: sum of R over the step time (per GPU), next to R+W above
+                    "read_only_GBps": round(read_bytes / (ms_per_step * 1e-3) / 1e9, 1),
+                    "read_only_frac": round(read_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
+        if per_rank is not None:
+            roofline["per_rank_frac"] = [round(8.0 * h / (f * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if f > 0 else 0.0 for f, h, _ in per_rank]
+            roofline["per_rank_step_ms"] = [round(e / args.steps * 1e3, 4) for _, _, e in per_rank]
+        gather_out = None
+        if gather_leg:
+            g_ms_step = gather_leg["elapsed"] / args.steps * 1e3
+            peers = [b for b in gather_leg["bytes_per_peer"] if b]
+            per_link = (max(peers) / (gather_leg["gather_ms"] * 1e-3) / 1e9) if peers and gather_leg["gather_ms"] > 0 else 0.0
+            gather_out = {"value": round(n_total_q * args.steps / gather_leg["elapsed"] / 1e6, 3), "unit": "M queries/s",
+                          "ms_per_step": round(g_ms_step, 4), "gather_ms": round(gather_leg["gather_ms"], 4),
+                          "bytes_per_peer_per_step": max(peers) if peers else 0,
+                          "per_link_GBps": round(per_link, 1), "per_link_frac_of_xgmi": round(per_link / XGMI_LINK_GBPS, 4),
+                          "root_ingress_GBps": round(sum(peers) / (gather_leg["gather_ms"] * 1e-3) / 1e9, 1) if peers and gather_leg["gather_ms"] > 0 else 0.0,
+                          "gathered_hits": gather_leg.get("gathered_hits"),
+                          "how": "dist.batch_isend_irecv: one grouped exchange, all peers' links at once, into buffers kept between "
+                                 "steps; the gather of step i overlaps the search of step i+1 (two handles, two compute streams)"}
+        if args.gather == "hits" and gather_out:
+            value, ms_per_step = gather_out["value"], gather_out["ms_per_step"]
         out = {
             "metric": "M queries/sec, DNA4 k=10 exact-match batch search, 1e8-bp text" if args.config == 2 else f"M queries/sec, BASELINE configs[{args.config - 1}] (informational)",
             "value": round(value, 3),
@@ -275,12 +486,11 @@ def main():
                                    f"(lengths {qlens}, planted share {planted}), materialised sorted position lists (to_vector), table={args.table}"
                                    f"{'(dense)' if info['tables'][0] == engine.TABLE_DENSE else '(open)'}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
-                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated", "gather": args.gather, "streams": n_streams, "pipeline_depth": depth},
-            "roofline": {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),
-                         "job_algorithmic_GBps": round(job_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                         "job_frac": round(job_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
+                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated",
+                       "gather": "hits" if args.gather == "hits" and gather_out else "totals", "pipeline_depth": depth},
+            "roofline": roofline,
+            "rccl": rccl,
+            "gather_hits": gather_out,
             "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
             "kernels_avg_ms": kernels_ms,
@@ -290,8 +500,9 @@ def main():
     for r_ in results:
         r_.close()
     idx.close()
-    if world > 1:
+    if backend is not None:
         dist.destroy_process_group()
+    return 0 if (verified is None or verified) else 4
 
 
 if __name__ == "__main__":

@@ -7,9 +7,9 @@ shards' outputs in rank order reproduces the single-GPU output byte for byte, so
 step is collecting results:
   * all_gather_totals : per-rank (n_queries, n_hits) — 16 bytes per rank, what a consumer needs to
                         address the sharded hit lists where they lie (the zero-copy mode bench.py times);
-  * gather_hit_lists  : the full gatherv of hit_off + positions to one rank (point-to-point
-                        send/recv with the displacements from the totals; over xGMI each shard
-                        crosses one direct link).
+  * HitGather.gather   : the full gatherv of hit_off + positions to one rank — one grouped point-to-point
+                        exchange with the displacements from the totals (over xGMI each shard crosses its
+                        own direct link, all W-1 links at once), into buffers kept between batches.
 Replicating the index is either "every rank builds it" (0.1 s on the GPU for 1e8 bp — what bench.py
 does) or build once + broadcast_index: the flat image of kmx_index_save as one broadcast payload.
 """
@@ -42,43 +42,85 @@ def all_gather_totals(n_queries: int, n_hits: int, device=None, group=None):
     return torch.stack(out).cpu().numpy()
 
 
-def gather_hit_lists(hit_off: torch.Tensor, positions: torch.Tensor, dst: int = 0, group=None):
-    """gatherv of the shards' results to rank `dst`.
+class HitGather:
+    """gatherv of the shards' results to rank `dst`, reusable across batches.
 
-    hit_off   : int64 [nq_local + 1], local offsets (hit_off[0] == 0)
-    positions : int32/uint32-as-int32 [n_hits_local]
-    Returns (hit_off_global int64 [nq_total + 1], positions_global) on `dst`, (None, None) elsewhere.
+    One call = one small all_gather (per-shard totals: the displacements) + ONE grouped point-to-point
+    exchange (`dist.batch_isend_irecv`: ncclGroupStart .. ncclGroupEnd on the nccl backend), in which the
+    root posts the receives from all W-1 peers at once, straight into their slices of the gathered
+    arrays — over xGMI every peer's shard then crosses its own direct link concurrently (W-1 links
+    busy, not one after the other).  The root's buffers are grow-only and kept between calls, so a
+    steady-state batch allocates nothing.
     """
-    rank = dist.get_rank(group)
-    world = dist.get_world_size(group)
-    device = hit_off.device
-    totals = all_gather_totals(hit_off.numel() - 1, positions.numel(), device=device, group=group)
-    if rank != dst:
-        if hit_off.numel() > 1:
-            dist.send(hit_off[1:].contiguous(), dst=dst, group=group)
-        if positions.numel():
-            dist.send(positions.contiguous(), dst=dst, group=group)
-        return None, None
-    nq_total = int(totals[:, 0].sum())
-    hits_total = int(totals[:, 1].sum())
-    g_off = torch.zeros(nq_total + 1, dtype=torch.int64, device=device)
-    g_pos = torch.empty(hits_total, dtype=positions.dtype, device=device)
-    q0, h0 = 0, 0
-    for r in range(world):
-        nq_r, nh_r = int(totals[r, 0]), int(totals[r, 1])
-        if r == dst:
-            g_off[q0 + 1:q0 + 1 + nq_r] = hit_off[1:] + h0
-            g_pos[h0:h0 + nh_r] = positions
-        else:
-            tmp = torch.empty(nq_r, dtype=torch.int64, device=device)
-            if nq_r:
-                dist.recv(tmp, src=r, group=group)
-            g_off[q0 + 1:q0 + 1 + nq_r] = tmp + h0
-            if nh_r:
-                dist.recv(g_pos[h0:h0 + nh_r], src=r, group=group)
-        q0 += nq_r
-        h0 += nh_r
-    return g_off, g_pos
+
+    def __init__(self, dst: int = 0, group=None):
+        self.dst, self.group = dst, group
+        self.g_off = None     # int64 [>= nq_total + 1]
+        self.g_pos = None     # positions' dtype [>= hits_total]
+        self.last_bytes_per_peer = []   # root only: bytes received from each peer in the last call (0 for itself)
+
+    def _ensure(self, nq_total, hits_total, device, pos_dtype):
+        if self.g_off is None or self.g_off.numel() < nq_total + 1 or self.g_off.device != device:
+            self.g_off = torch.empty(nq_total + 1 + (nq_total >> 4), dtype=torch.int64, device=device)
+        if self.g_pos is None or self.g_pos.numel() < hits_total or self.g_pos.device != device or self.g_pos.dtype != pos_dtype:
+            self.g_pos = torch.empty(hits_total + (hits_total >> 4), dtype=pos_dtype, device=device)
+
+    def gather(self, hit_off: torch.Tensor, positions: torch.Tensor, totals=None):
+        """hit_off int64 [nq_local + 1] (hit_off[0] == 0), positions [n_hits_local] (n_hits_local == hit_off[-1]).
+        `totals` ([world, 2] int64 numpy, from all_gather_totals) may be passed by a caller that already has them.
+        Returns (hit_off_global int64 [nq_total + 1], positions_global) on `dst` — views of the kept buffers, valid
+        until the next call — and (None, None) elsewhere."""
+        group, dst = self.group, self.dst
+        rank = dist.get_rank(group)
+        world = dist.get_world_size(group)
+        device = hit_off.device
+        nq_local = hit_off.numel() - 1
+        if totals is None:
+            totals = all_gather_totals(nq_local, positions.numel(), device=device if device.type == "cuda" else None, group=group)
+        if rank != dst:
+            ops = []
+            peer = dist.get_global_rank(group, dst) if group is not None else dst
+            if nq_local:
+                ops.append(dist.P2POp(dist.isend, hit_off[1:], peer, group))
+            if positions.numel():
+                ops.append(dist.P2POp(dist.isend, positions, peer, group))
+            for w in (dist.batch_isend_irecv(ops) if ops else []):
+                w.wait()
+            return None, None
+        nq_total = int(totals[:, 0].sum())
+        hits_total = int(totals[:, 1].sum())
+        self._ensure(nq_total, hits_total, device, positions.dtype)
+        g_off, g_pos = self.g_off[:nq_total + 1], self.g_pos[:hits_total]
+        g_off[0] = 0
+        ops, rebase = [], []
+        self.last_bytes_per_peer = [0] * world
+        q0, h0 = 0, 0
+        for r in range(world):
+            nq_r, nh_r = int(totals[r, 0]), int(totals[r, 1])
+            if r == dst:
+                torch.add(hit_off[1:], h0, out=g_off[q0 + 1:q0 + 1 + nq_r])
+                g_pos[h0:h0 + nh_r].copy_(positions)
+            else:
+                peer = dist.get_global_rank(group, r) if group is not None else r
+                if nq_r:
+                    ops.append(dist.P2POp(dist.irecv, g_off[q0 + 1:q0 + 1 + nq_r], peer, group))
+                    if h0:
+                        rebase.append((q0 + 1, q0 + 1 + nq_r, h0))
+                if nh_r:
+                    ops.append(dist.P2POp(dist.irecv, g_pos[h0:h0 + nh_r], peer, group))
+                self.last_bytes_per_peer[r] = nq_r * 8 + nh_r * g_pos.element_size()
+            q0 += nq_r
+            h0 += nh_r
+        for w in (dist.batch_isend_irecv(ops) if ops else []):
+            w.wait()
+        for a, b, h in rebase:                      # the peers sent shard-local offsets
+            g_off[a:b] += h
+        return g_off, g_pos
+
+
+def gather_hit_lists(hit_off: torch.Tensor, positions: torch.Tensor, dst: int = 0, group=None):
+    """One-shot form of HitGather.gather (fresh buffers)."""
+    return HitGather(dst, group).gather(hit_off, positions)
 
 
 def broadcast_bytes(data, src: int = 0, device=None, group=None) -> np.ndarray:

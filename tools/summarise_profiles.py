@@ -37,9 +37,12 @@ def counters(path, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--round", default="r01")
+    ap.add_argument("--round", default="r02")
+    ap.add_argument("--config", type=int, default=2)
     a = ap.parse_args()
-    src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}")
+    sfx = "" if a.config == 2 else f"_cfg{a.config}"
+    src = os.path.join(ROOT, "gpurun_out", f"prof_{a.tag}{sfx}")
+    a.tag += sfx
     dst = os.path.join(ROOT, "profiles")
     bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
     with open(os.path.join(dst, f"{a.round}_bench_{a.tag}.json"), "w") as f:
@@ -74,10 +77,10 @@ def main():
         for row in csv.DictReader(f):
             if row["Counter_Name"] == "FETCH_SIZE" and "k_scan_reduce" in row["Kernel_Name"] and float(row["Counter_Value"]) > red:
                 red, red_items = float(row["Counter_Value"]), int(row["Grid_Size"]) // 256 * 4096
-    fill = next(k for k in kernels if k.startswith("kmx::k_fill<"))
+    fill = max((k for k in kernels if k.startswith("kmx::k_fill<")), key=lambda k: kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches"])
     out = {
         "source": f"tools/profile_round.sh {a.tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
-                  "--kernel-trace --stats, each over `python3 bench.py --no-cpu-baseline --no-open-compare --steps 8 --warmup 2`, MI355X",
+                  "--kernel-trace --stats, each over `python3 bench.py" + (f" --config {a.config}" if a.config != 2 else "") + " --no-cpu-baseline --no-open-compare --steps 8 --warmup 2`, MI355X",
         "units": "FETCH_SIZE / WRITE_SIZE are KiB as reported; fetch_bytes_corrected doubles FETCH_SIZE (gfx950 tallies 128-B "
                  "requests at 64 B, MI355X_MICROARCH.md HBM section); calibration in the same run: the largest k_scan_reduce "
                  f"launch reads exactly 4 B x {red_items} items = {4 * red_items} B",
@@ -94,7 +97,7 @@ def main():
             "avg_launch_ms_bench_hip_events": bench["roofline"]["avg_launch_ms"],
         },
     }
-    for name in (f"{a.round}_pmc_summary_{a.tag}.json", "pmc_summary_current.json"):
+    for name in (f"{a.round}_pmc_summary_{a.tag}.json", f"pmc_summary_current{sfx}.json"):
         with open(os.path.join(dst, name), "w") as f:
             json.dump(out, f, indent=1)
     print(json.dumps(out["k_fill"], indent=1))
