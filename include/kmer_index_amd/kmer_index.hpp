@@ -61,8 +61,11 @@ namespace kmer
         using result_t = detail::kmer_index_result<position_t>;
 
         // kmer_index.hpp:480-496 — one flattened element per k (built on n_threads host threads) + planner
+        // `devices` (new): the GPUs to replicate the index on; empty = the current device, or every device the
+        // environment variable KMX_DEVICES names ("all" / "0,1,..."), so that an unchanged caller of
+        // make_kmer_index<ks...>(text) can be given the whole node.  Batch searches shard over the replicas.
         template<std::ranges::range text_t>
-        kmer_index(text_t& text, std::size_t n_threads = std::max(std::thread::hardware_concurrency(), 1u))
+        kmer_index(text_t& text, std::size_t n_threads = std::max(std::thread::hardware_concurrency(), 1u), const std::vector<int>& devices = {})
         {
             std::vector<std::uint8_t> ranks;
             ranks.reserve(std::ranges::size(text));
@@ -73,6 +76,10 @@ namespace kmer
             opts.device = -1;
             opts.n_threads = std::uint32_t(n_threads);
             opts.keep_host_arena = 1;
+            if (devices.size() > KMX_MAX_DEVICES) throw std::invalid_argument("kmer_index: more than KMX_MAX_DEVICES devices");
+            opts.n_devices = std::uint32_t(devices.size());
+            for (std::size_t i = 0; i < devices.size(); ++i) opts.devices[i] = devices[i];
+            if (!devices.empty()) opts.device = devices[0];
             kmx_index* raw = nullptr;
             detail::throw_on(kmx_index_build(ranks.data(), ranks.size(), std::uint32_t(traits::size), k_arr, sizeof...(ks), &opts, &raw),
                              "kmer_index");
@@ -113,8 +120,10 @@ namespace kmer
             _query_size_range = new_maximum;
         }
 
-        // batch search: one GPU pass over all queries; results share the batch's buffers
-        std::vector<result_t> search(const std::vector<std::vector<alphabet_t>>& queries) const
+        // batch search: one GPU pass over all queries; results share the batch's buffers.
+        // Per-query errors do not cost the batch: `status_out` receives one kmx_query_status per query and a query that
+        // the reference would throw for (too long :507-509, sub-k fan-out :119-122, empty :195) gets an empty result.
+        std::vector<result_t> search(const std::vector<std::vector<alphabet_t>>& queries, std::vector<std::uint8_t>& status_out) const
         {
             std::vector<std::uint8_t> ranks;
             std::vector<std::uint64_t> off(queries.size() + 1, 0);
@@ -131,30 +140,54 @@ namespace kmer
             const std::uint64_t* mask_base; const std::uint64_t* mask_words; const std::uint32_t* cand_count; const std::uint64_t* cand_src;
             detail::throw_on(kmx_result_masks(raw, &mask_base, &mask_words, &cand_count, &cand_src), "search");
 
+            status_out.assign(status, status + queries.size());
             std::vector<result_t> out;
             out.reserve(queries.size());
             for (std::size_t i = 0; i < queries.size(); ++i)
             {
-                switch (status[i])
-                {
-                    case KMX_Q_OK: break;
-                    case KMX_Q_TOO_LONG:       // kmer_index.hpp:507-509
-                        throw std::invalid_argument("query size exceed the maximum size " + std::to_string(_query_size_range) + " specified");
-                    case KMX_Q_SUBK_FANOUT:    // kmer_index.hpp:119-122
-                        throw std::invalid_argument("query size too low for specified k");
-                    case KMX_Q_EMPTY_QUERY:    // assert(query.size() > 0), kmer_index.hpp:195
-                        throw std::invalid_argument("query must not be empty");
-                    default:
-                        throw std::invalid_argument("query holds a letter outside the alphabet");
-                }
                 const position_t* hits = positions ? positions + hit_off[i] : nullptr;
                 const std::size_t n_hits = std::size_t(hit_off[i + 1] - hit_off[i]);
-                if (kinds[i] == KMX_KIND_STITCH)
-                    out.emplace_back(handle, hits, n_hits, _arena + cand_src[i], std::size_t(cand_count[i]), mask_words + mask_base[i]);
-                else if (kinds[i] == KMX_KIND_NONE)
+                if (status[i] != KMX_Q_OK || kinds[i] == KMX_KIND_NONE)
                     out.emplace_back();
+                else if (kinds[i] == KMX_KIND_STITCH)
+                    out.emplace_back(handle, hits, n_hits, _arena + cand_src[i], std::size_t(cand_count[i]), mask_words + mask_base[i]);
                 else
                     out.emplace_back(handle, hits, n_hits);
+            }
+            return out;
+        }
+
+        // the same, with the reference's error behaviour: std::invalid_argument (a batch_query_error that also carries
+        // the index of the first offending query, every query's status and the results of the others)
+        struct batch_query_error : std::invalid_argument
+        {
+            std::size_t query_index;
+            std::vector<std::uint8_t> status;
+            std::vector<result_t> results;
+            batch_query_error(const std::string& what, std::size_t i, std::vector<std::uint8_t> st, std::vector<result_t> res)
+                : std::invalid_argument(what), query_index(i), status(std::move(st)), results(std::move(res)) {}
+        };
+
+        std::vector<result_t> search(const std::vector<std::vector<alphabet_t>>& queries) const
+        {
+            std::vector<std::uint8_t> status;
+            std::vector<result_t> out = search(queries, status);
+            for (std::size_t i = 0; i < status.size(); ++i)
+            {
+                std::string what;
+                switch (status[i])
+                {
+                    case KMX_Q_OK: continue;
+                    case KMX_Q_TOO_LONG:       // kmer_index.hpp:507-509
+                        what = "query size exceed the maximum size " + std::to_string(_query_size_range) + " specified"; break;
+                    case KMX_Q_SUBK_FANOUT:    // kmer_index.hpp:119-122
+                        what = "query size too low for specified k"; break;
+                    case KMX_Q_EMPTY_QUERY:    // assert(query.size() > 0), kmer_index.hpp:195
+                        what = "query must not be empty"; break;
+                    default:
+                        what = "query holds a letter outside the alphabet"; break;
+                }
+                throw batch_query_error(what, i, std::move(status), std::move(out));
             }
             return out;
         }
@@ -184,6 +217,15 @@ namespace kmer
         }
 
         const kmx_index* handle() const { return _index.get(); }
+
+        // the devices this index is replicated on
+        std::vector<int> devices() const
+        {
+            std::uint32_t n = 0;
+            std::int32_t d[KMX_MAX_DEVICES] = {};
+            detail::throw_on(kmx_index_devices(_index.get(), &n, d), "devices");
+            return std::vector<int>(d, d + n);
+        }
     };
 
     // choose_best_k.hpp:12-60 — which ks to instantiate for a set of query lengths
@@ -199,10 +241,10 @@ namespace kmer
 
     // kmer_index.hpp:569-579
     template<std::size_t... ks, std::ranges::range text_t>
-    auto make_kmer_index(text_t&& text, std::size_t n_threads = std::thread::hardware_concurrency())
+    auto make_kmer_index(text_t&& text, std::size_t n_threads = std::thread::hardware_concurrency(), const std::vector<int>& devices = {})
     {
         using alphabet_t = std::remove_cvref_t<std::ranges::range_value_t<text_t>>;
         using position_t = std::uint32_t;
-        return kmer_index<alphabet_t, position_t, ks...>(text, std::max<std::size_t>(n_threads, 1));
+        return kmer_index<alphabet_t, position_t, ks...>(text, std::max<std::size_t>(n_threads, 1), devices);
     }
 } // namespace kmer

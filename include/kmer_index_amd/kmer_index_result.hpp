@@ -10,6 +10,11 @@
 //   * size() returns the number of valid positions (the reference counts mask bits and so
 //     returns 0 for bypass and sub-k results, kmer_index_result.hpp:239-242);
 //   * begin()/end() work (the reference's iterator does not instantiate, :182).
+// should_use(i) / should_not_use(i) are MUTATORS as in the reference (:228-236): they set / clear bit i of the
+// result's own copy of the mask, and to_vector() / size() / begin() / at() follow the edited mask from then on
+// (the hits are re-derived from the candidate run, which is ascending, so the list stays sorted).  On a result that
+// bypasses its mask (exact and sub-k lookups) the mask has 0 bits and both throw std::out_of_range, exactly what
+// compressed_bitset::set_0 / set_1 do in the reference for such a result.  The const predicate is is_valid(i).
 #pragma once
 #include <cstddef>
 #include <cstdint>
@@ -35,6 +40,17 @@ namespace kmer::detail
         std::size_t _n_candidates = 0;
         compressed_bitset<std::uint_fast64_t> _bitmask; // validity over the candidates
         bool _bypass_bitmask = true;
+        std::shared_ptr<std::vector<position_t>> _edited; // hits re-derived after should_use / should_not_use
+
+        void rederive()
+        {
+            auto v = std::make_shared<std::vector<position_t>>();
+            for (std::size_t i = 0; i < _n_candidates; ++i)
+                if (_bitmask.at(i)) v->push_back(_candidates[i]);
+            _edited = std::move(v);
+            _hits = _edited->data();
+            _n_hits = _edited->size();
+        }
 
     public:
         using const_iterator = const position_t*;
@@ -68,9 +84,9 @@ namespace kmer::detail
         }
         position_t operator[](std::size_t i) const { return _hits[i]; }
 
-        // should_use / should_not_use (kmer_index_result.hpp:228-236): validity of candidate i
-        bool should_use(std::size_t i) const { return is_valid(i); }
-        bool should_not_use(std::size_t i) const { return !is_valid(i); }
+        // specify which positions to use by setting the bitmask (kmer_index_result.hpp:228-236)
+        void should_not_use(std::size_t i) { _bitmask.set_0(i); rederive(); }
+        void should_use(std::size_t i) { _bitmask.set_1(i); rederive(); }
 
         // the zero-copy view of the reference: candidates + validity mask
         bool bypasses_bitmask() const { return _bypass_bitmask; }

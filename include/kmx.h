@@ -16,7 +16,9 @@
  *     the library until kmx_result_free;
  *   - one kmx_index may be searched from several host threads at once (the
  *     reference's search() is const, kmer_index.hpp:505) provided each call uses
- *     its own stream and result handle;
+ *     its own result handle (and, for the device-buffer form, its own stream): the
+ *     host-buffer form runs on a stream owned by the result, so concurrent calls
+ *     overlap on the GPU instead of queueing behind one another;
  *   - the engine needs the HIP runtime and a gfx950 device: there is no CPU path.
  */
 #ifndef KMX_H
@@ -29,8 +31,9 @@
 extern "C" {
 #endif
 
-#define KMX_VERSION 1
+#define KMX_VERSION 2
 #define KMX_MAX_KS 32               /* number of k values one index may hold                      */
+#define KMX_MAX_DEVICES 16          /* replicas of one index (one per GPU of a node)              */
 #define KMX_QUERY_SIZE_RANGE 10000  /* kmer_index::_query_size_range, kmer_index.hpp:401          */
 #define KMX_SUBK_FANOUT_LIMIT 10000000ull /* sigma^(k-m) guard, kmer_index.hpp:119                */
 
@@ -79,6 +82,17 @@ typedef struct kmx_options {
                                   key space allows (sigma^k <= 2^26), host otherwise                     */
     uint32_t no_aligned_copy;  /* 1 = do not keep the second, 128-byte-line-aligned copy of long buckets (saves
                                   up to ~1.2x the position array; exact lookups then read ~13 % more)      */
+    /* ---- since KMX_VERSION 2 (a caller compiled against version 1 passes the shorter struct_size and gets one replica) ---- */
+    uint32_t n_devices;        /* 0 / 1: one replica on `device`.  N > 1: the index is built once on devices[0] and its flat
+                                  image replicated (device-to-device copies) into the HBM of devices[1..N-1]; a host-buffer
+                                  batch search then shards the queries contiguously over the replicas — replica r gets queries
+                                  [nq*r/N, nq*(r+1)/N) — and returns ONE result whose views concatenate the shards in replica
+                                  order, byte for byte what one device returns (batches of fewer than 256 queries per
+                                  replica go to the first replica whole).  0 also reads the environment
+                                  variable KMX_DEVICES ("all" or a comma-separated list of ordinals), so that a caller of
+                                  kmer::make_kmer_index uses every GPU of the node without a code change.  An ordinal may be
+                                  listed more than once (replicas then share a device: only useful for testing).           */
+    int32_t devices[KMX_MAX_DEVICES];
 } kmx_options;
 
 /* kmx_search_batch flags */
@@ -88,8 +102,9 @@ typedef struct kmx_options {
 #define KMX_SEARCH_ASYNC 4u        /* device form only: return once the first half of the search is enqueued (lookup,
                                       scan, the steady-state fill) without waiting for the counters; the search is
                                       completed by whatever touches the result next (counts / view / masks / free / a
-                                      new search into it).  The index, d_qranks and d_qoff must stay alive until then.
-                                      Two results used in turn keep the GPU busy across batches. */
+                                      new search into it, or kmx_index_free of its index, which completes every search
+                                      still pending on the index before it releases anything).  d_qranks and d_qoff must
+                                      stay alive until then.  Two results used in turn keep the GPU busy across batches. */
 
 typedef struct kmx_index kmx_index;
 typedef struct kmx_result kmx_result;
@@ -113,7 +128,10 @@ void kmx_index_free(kmx_index* index);
 
 /* On-disk image of the flattened index: build once, load many (the intent stated in the thesis,
  * thesis/content/02_implementation.tex:44-46; not implemented by the reference).  kmx_index_load validates
- * magic, version, every size field and a checksum before touching the device. */
+ * magic, version, every size field and a checksum, and then the CONTENTS the kernels index with — group boundaries
+ * monotone and ending at npos, distinct keys strictly ascending and inside the key space, at most half of the
+ * open-addressing slots occupied (a full table would make the probe loop spin), every slot's and every aligned-table
+ * entry's run inside the element's region, positions inside the text — before touching the device. */
 kmx_status kmx_index_save(const kmx_index* index, const char* path);
 kmx_status kmx_index_load(const char* path, const kmx_options* opts, kmx_index** out);
 
@@ -152,7 +170,8 @@ uint64_t kmx_fast_pow(uint64_t base, uint8_t exp);
 kmx_status kmx_search_batch(const kmx_index* index, const uint8_t* qranks, const uint64_t* qoff,
                             uint64_t nq, uint32_t flags, kmx_result** out);
 
-/* Device-buffer form: d_qranks / d_qoff are device pointers already resident in HBM,
+/* Device-buffer form: d_qranks / d_qoff are device pointers already resident in HBM (on an index with several replicas: in
+ * the HBM of any of its devices — the replica on the device that owns d_qranks serves the call),
  * `stream` is a hipStream_t (NULL = the default stream).  All kernels are enqueued on
  * `stream`; the call returns after the one host read-back it needs (per-kind counts
  * and the hit total, 64 bytes) and with the fill kernels enqueued.  Passing a result
@@ -174,6 +193,16 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
                                   const uint32_t** d_positions, const uint8_t** d_status);
 kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32_t** positions,
                            const uint8_t** status, const uint8_t** kinds);
+
+/* Multi-device results.  A result of a host-buffer search on an index with N replicas has N parts, part p holding
+ * the queries [q_begin, q_end) on `device`; kmx_result_view / kmx_result_masks / kmx_result_counts present the parts as one
+ * result, kmx_result_view_device is refused for N > 1 (there is no single device to point into) — use the per-part device
+ * views, whose hit_off is local to the part (hit_off[0] == 0).  Every other result has exactly one part. */
+kmx_status kmx_result_parts(const kmx_result* r, uint32_t* n_parts);
+kmx_status kmx_result_part_view_device(const kmx_result* r, uint32_t part, int32_t* device, uint64_t* q_begin, uint64_t* q_end,
+                                       const uint64_t** d_hit_off, const uint32_t** d_positions, const uint8_t** d_status);
+/* The devices an index is replicated on (devices[] holds KMX_MAX_DEVICES entries). */
+kmx_status kmx_index_devices(const kmx_index* index, uint32_t* n_devices, int32_t* devices);
 
 /* KMX_SEARCH_KEEP_MASKS only — the reference's zero-copy result view
  * (kmer_index_result.hpp:15-24: pointers to bucket vectors + a compressed_bitset).

@@ -149,10 +149,12 @@ struct Stats {
 // Results released with kmx_result_free wait here for the next search that arrives without a result of its
 // own: a fresh result costs some twenty device allocations, which dominates the latency of small batches
 // (kmer_index::search(query) is a batch of one).  Shared between the index and its results, so a result may
-// outlive its index.
+// outlive its index: a search still pending on a result (KMX_SEARCH_ASYNC) is listed here and completed by
+// kmx_index_free before the index releases anything the second half would touch.
 struct ResultPool {
     std::mutex mu;
     std::vector<kmx_result*> idle;
+    std::vector<kmx_result*> pending;    // KMX_SEARCH_ASYNC searches whose second half has not run yet: kmx_index_free completes them
     bool closed = false;
 };
 constexpr size_t kPoolMaxResults = 8;
@@ -179,9 +181,10 @@ struct kmx_index {
     kmx::FillVariant fill_variant{12, true};   // 3072-slot tiles (12 gathers in flight per thread), non-temporal stores
     bool rec32 = true;                   // every arena index fits 31 bits
     std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
-    hipStream_t stream = nullptr;       // internal stream of the host-buffer search form
-    std::mutex host_call_mu;
     Stats stats;
+    std::vector<kmx_index*> peers;      // replicas 1..N-1 of a multi-device index (owned by replica 0, which is this object)
+    size_t n_replicas() const { return 1 + peers.size(); }
+    kmx_index* replica(size_t i) { return i ? peers[i - 1] : this; }
 };
 
 // What search_finish needs from the call that enqueued the first half of a search.
@@ -196,7 +199,8 @@ struct SearchCtx {
 };
 
 struct kmx_result {
-    const kmx_index* index = nullptr;   // identity only: never dereferenced after the search call returns
+    const kmx_index* index = nullptr;   // the index of the last search; dereferenced only while that search is pending (ctx.pending),
+                                        // and kmx_index_free completes pending searches before the index goes away
     int device = 0;
     hipStream_t stream = nullptr;
     uint32_t flags = 0;
@@ -215,6 +219,13 @@ struct kmx_result {
     SearchCtx ctx;                         // the half-done search of a KMX_SEARCH_ASYNC call (search_finish completes it)
     hipEvent_t done = nullptr;             // recorded behind the first half's counter read-back
     bool quiesced = true;                  // no kernel of the last search can still be running on `stream`
+    hipStream_t own_stream = nullptr;      // the stream of the host-buffer search form: one per result, so concurrent
+                                           // kmx_search_batch calls on one index do not serialise behind a shared stream
+    // a result over several replicas (host-buffer search on a multi-device index): the per-device results, in replica
+    // order, and the first query of each (part_q0[n_parts] == nq).  The parent owns no device buffers.
+    std::vector<kmx_result*> parts;
+    std::vector<uint64_t> part_q0;
+    std::vector<uint64_t> part_w0;         // first mask word of each part in the merged mask view
 
     size_t device_bytes() const
     {
@@ -236,6 +247,8 @@ struct kmx_result {
         h_ctr = nullptr;
         if (done) (void)hipEventDestroy(done);
         done = nullptr;
+        if (own_stream) (void)hipStreamDestroy(own_stream);
+        own_stream = nullptr;
     }
 };
 
@@ -425,6 +438,9 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
                 el.dir_shift = key_bits - D;
                 el.n_dir = 1u << D;
                 kmx::launch_build_dir(nullptr, el.ukeys, el.n_ukeys, el.dir_shift, el.n_dir, static_cast<uint32_t*>(p));
+                hipError_t le = hipGetLastError();
+                if (le == hipSuccess) le = hipDeviceSynchronize();
+                if (le != hipSuccess) { fail(KMX_ERR_HIP, std::string("key directory: ") + hipGetErrorString(le)); return bail(KMX_ERR_HIP); }
             } else {
                 (void)hipGetLastError();                            // no directory: the searches run over the whole key array
             }
@@ -444,12 +460,137 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         ix->d_index = const_cast<KmxIndexDev*>(d);
         ix->h_header = h;
     }
+    *out = ix;
+    return KMX_OK;
+}
+
+// A second replica of `src` in the HBM of `device`: every array of the flat image copied device to device
+// (hipMemcpyPeer: over xGMI between two GPUs of a node), the header rebuilt around the new pointers.
+static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** out)
+{
+    auto* ix = new kmx_index();
+    ix->device = device;
+    ix->n = src->n; ix->sigma = src->sigma; ix->range = src->range;
+    ix->ks = src->ks; ix->table_kinds = src->table_kinds; ix->elem_sizes = src->elem_sizes; ix->tail = src->tail;
+    ix->fill_variant = src->fill_variant; ix->rec32 = src->rec32;
+    auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
+    hipError_t e = hipSetDevice(device);
+    if (e != hipSuccess) { fail(KMX_ERR_NO_DEVICE, std::string("replica device: ") + hipGetErrorString(e)); return bail(KMX_ERR_NO_DEVICE); }
+    kmx_status st = KMX_OK;
+    auto clone = [&](const void* sp, size_t bytes, size_t pad, const void** dp) -> bool {
+        *dp = nullptr;
+        if (!sp) return true;
+        void* p = nullptr;
+        hipError_t e2 = hipMalloc(&p, std::max<size_t>(bytes, 16) + pad);
+        if (e2 != hipSuccess) { st = fail(KMX_ERR_OUT_OF_MEMORY, std::string("replica: ") + hipGetErrorString(e2)); return false; }
+        ix->allocs.push_back(p);
+        ix->device_bytes += bytes;
+        if (bytes) {
+            e2 = hipMemcpyPeer(p, device, sp, src->device, bytes);
+            if (e2 != hipSuccess) { st = fail(KMX_ERR_HIP, std::string("replica copy: ") + hipGetErrorString(e2)); return false; }
+        }
+        *dp = p;
+        return true;
+    };
+    KmxIndexDev h = src->h_header;
+    const void* p = nullptr;
+    if (!clone(src->h_header.arena, h.arena_elems * 4 + 64, 0, &p)) return bail(st);
+    h.arena = static_cast<const uint32_t*>(p); ix->d_arena = h.arena;
+    if (!clone(src->h_header.tail, h.kmax, 16, &p)) return bail(st);
+    h.tail = static_cast<const uint8_t*>(p);
+    if (!clone(src->h_header.plan, size_t(h.range) * sizeof(KmxPlanEntry), 16, &p)) return bail(st);
+    h.plan = static_cast<const KmxPlanEntry*>(p);
     {
-        hipError_t e = hipStreamCreateWithFlags(&ix->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("stream: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+        void* d = nullptr;
+        if (hipMalloc(&d, 16 * 8) == hipSuccess) { (void)hipMemset(d, 0, 16 * 8); ix->allocs.push_back(d); h.dbg = static_cast<unsigned long long*>(d); ix->d_dbg = h.dbg; }
+        else { (void)hipGetLastError(); h.dbg = nullptr; }
+    }
+    for (uint32_t i = 0; i < h.n_ks; ++i) {
+        const KmxElemDev& se = src->h_header.elems[i];
+        KmxElemDev& de = h.elems[i];
+        const auto& sz = src->elem_sizes[i];
+        if (!clone(se.offs, sz.n_offs * 4, 16, &p)) return bail(st);
+        de.offs = static_cast<const uint32_t*>(p);
+        if (!clone(se.atab, sz.n_aoffs * 4, 16, &p)) return bail(st);
+        de.atab = static_cast<const uint32_t*>(p);
+        if (!clone(se.slots, sz.n_slots * sizeof(KmxSlot), 16, &p)) return bail(st);
+        de.slots = static_cast<const KmxSlot*>(p);
+        if (!clone(se.ukeys, sz.n_ukeys * 8, 16, &p)) return bail(st);
+        de.ukeys = static_cast<const uint64_t*>(p);
+        if (!clone(se.dir, se.dir ? (size_t(se.n_dir) + 1) * 4 : 0, 64, &p)) return bail(st);
+        de.dir = static_cast<const uint32_t*>(p);
+    }
+    if (!clone(nullptr, 0, 0, &p)) return bail(st);
+    {
+        void* d = nullptr;
+        e = hipMalloc(&d, sizeof(KmxIndexDev) + 16);
+        if (e == hipSuccess) { ix->allocs.push_back(d); e = hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice); }
+        if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("replica header: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+        ix->d_index = static_cast<KmxIndexDev*>(d);
+        ix->h_header = h;
     }
     *out = ix;
     return KMX_OK;
+}
+
+// Resolves the replica set an options struct (or the KMX_DEVICES environment variable) asks for and clones the freshly
+// built / loaded primary onto the other devices.  Leaves the caller's current device as it found it.
+static kmx_status add_replicas(kmx_index* ix, const kmx_options& o)
+{
+    std::vector<int> devs;
+    if (o.n_devices > 1) {
+        if (o.n_devices > KMX_MAX_DEVICES) return fail(KMX_ERR_INVALID_ARGUMENT, "options.n_devices exceeds KMX_MAX_DEVICES");
+        devs.assign(o.devices, o.devices + o.n_devices);
+    } else if (o.n_devices == 0) {
+        if (const char* env = getenv("KMX_DEVICES")) {
+            int count = 0;
+            (void)hipGetDeviceCount(&count);
+            if (!strcmp(env, "all")) { for (int d = 0; d < count && d < KMX_MAX_DEVICES; ++d) devs.push_back(d); }
+            else {
+                for (const char* c = env; *c;) {
+                    char* end = nullptr;
+                    long v = strtol(c, &end, 10);
+                    if (end == c) return fail(KMX_ERR_INVALID_ARGUMENT, "KMX_DEVICES: expected \"all\" or a comma-separated list of device ordinals");
+                    devs.push_back(int(v));
+                    c = (*end == ',') ? end + 1 : end;
+                    if (*end && *end != ',') return fail(KMX_ERR_INVALID_ARGUMENT, "KMX_DEVICES: expected \"all\" or a comma-separated list of device ordinals");
+                }
+                if (devs.size() > KMX_MAX_DEVICES) return fail(KMX_ERR_INVALID_ARGUMENT, "KMX_DEVICES lists more than KMX_MAX_DEVICES devices");
+            }
+            // the primary already lives on options.device / the current device: it becomes (or stays) the first replica
+            auto it = std::find(devs.begin(), devs.end(), ix->device);
+            if (it != devs.end()) std::rotate(devs.begin(), it, it + 1);
+            else if (!devs.empty()) devs.insert(devs.begin(), ix->device);
+        }
+    }
+    if (devs.size() < 2) return KMX_OK;
+    int count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    for (int d : devs)
+        if (d < 0 || d >= count) return fail(KMX_ERR_NO_DEVICE, "a device of the replica list is not visible (" + std::to_string(d) + " of " + std::to_string(count) + ")");
+    kmx_status st = KMX_OK;
+    for (size_t i = 1; i < devs.size() && st == KMX_OK; ++i) {
+        kmx_index* rep = nullptr;
+        st = replicate_index(ix, devs[i], &rep);
+        if (st == KMX_OK) { rep->pool = std::make_shared<ResultPool>(); ix->peers.push_back(rep); }
+    }
+    (void)hipSetDevice(ix->device);
+    return st;
+}
+
+// kmx_options as this library version understands it, from a caller's struct of either version
+static bool read_options(const kmx_options* opts, kmx_options& o)
+{
+    o = kmx_options{};
+    o.struct_size = sizeof(kmx_options);
+    o.device = -1;
+    if (!opts) return true;
+    const size_t v1 = offsetof(kmx_options, n_devices);
+    if (opts->struct_size != sizeof(kmx_options) && opts->struct_size != v1) return false;
+    memcpy(&o, opts, opts->struct_size);
+    o.struct_size = sizeof(kmx_options);
+    if (opts->struct_size == v1) o.n_devices = 1;          // a version-1 caller: one replica, no environment override
+    return true;
 }
 
 
@@ -512,13 +653,9 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
     *out = nullptr;
     if (!ranks || !ks || n_ks == 0 || n_ks > KMX_MAX_KS)
         return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: need ranks and 1..KMX_MAX_KS values of k");
-    kmx_options o{};
-    o.device = -1;
-    if (opts) {
-        if (opts->struct_size != sizeof(kmx_options))
-            return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: options.struct_size mismatch");
-        o = *opts;
-    }
+    kmx_options o;
+    if (!read_options(opts, o)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_build: options.struct_size mismatch");
+    if (o.n_devices > 1) o.device = o.devices[0];
     uint32_t kmax = 0;
     for (uint32_t i = 0; i < n_ks; ++i) {
         if (!kmx::k_is_valid(sigma, ks[i]))
@@ -603,6 +740,8 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
             e = hipMalloc(reinterpret_cast<void**>(&dev[i].d_offs), (nk + 1) * 4 + 64);
             if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("offs: ") + hipGetErrorString(e)); }
             kmx::launch_build_phase1(nullptr, d_text, n, ks[i], sigma, nk, d_hist, d_scr, d_bsum, dev[i].d_offs, d_cursor, d_info, d_total);
+            e = hipGetLastError();                                  // a rejected launch is not reported by the copies below
+            if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_HIP, std::string("device build (launch): ") + hipGetErrorString(e)); }
             unsigned int info[4] = {0, 0, 0, 0};
             unsigned long long totals[2] = {0, 0};
             e = hipMemcpy(info, d_info, sizeof info, hipMemcpyDeviceToHost);                      // also synchronises
@@ -703,7 +842,8 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         if (e == hipSuccess) {
             kmx::launch_build_phase2(nullptr, d_text, n, ks[i], sigma, im.n_keys, dev[i].d_offs, d_hist, d_scr, d_bsum, d_cursor, d_info, d_total,
                                      d_region, dev[i].d_aoffs, uint32_t(dev[i].a0), sort_mode, dev[i].d_atab, uint32_t(im.region));
-            e = hipDeviceSynchronize();
+            e = hipGetLastError();                                  // a rejected launch (e.g. the 128 KB dynamic-LDS block sort) would
+            if (e == hipSuccess) e = hipDeviceSynchronize();        // leave buckets unsorted without any later call noticing
         }
         if (e != hipSuccess) { free_dev(); free_sparse(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("device build: ") + hipGetErrorString(e)); }
         if (im.table_kind == KMX_TABLE_DENSE) {
@@ -735,14 +875,30 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         }
     }
 
-    return install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena);
+    st = install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena);
+    if (st != KMX_OK) return st;
+    st = add_replicas(*out, o);
+    if (st != KMX_OK) { std::string keep = g_err; kmx_index_free(*out); *out = nullptr; g_err = keep; }
+    return st;
 }
+
+static kmx_status search_finish(kmx_result* r);
 
 void kmx_index_free(kmx_index* ix)
 {
     if (!ix) return;
+    for (kmx_index* peer : ix->peers) kmx_index_free(peer);
+    ix->peers.clear();
     (void)hipSetDevice(ix->device);
     {
+        // searches still pending on live results (KMX_SEARCH_ASYNC) would launch kernels on this index's memory when
+        // their result is next touched: complete them now, while everything is still there
+        std::vector<kmx_result*> pending;
+        {
+            std::lock_guard<std::mutex> lock(ix->pool->mu);
+            pending = ix->pool->pending;
+        }
+        for (kmx_result* r : pending) (void)search_finish(r);
         std::vector<kmx_result*> idle;
         {
             std::lock_guard<std::mutex> lock(ix->pool->mu);
@@ -751,8 +907,8 @@ void kmx_index_free(kmx_index* ix)
         }
         for (kmx_result* r : idle) { r->release(); delete r; }
     }
+    (void)hipDeviceSynchronize();          // nothing of a completed search is still reading the image
     ix->stats.destroy();
-    if (ix->stream) (void)hipStreamDestroy(ix->stream);
     for (void* p : ix->allocs) (void)hipFree(p);
     delete ix;
 }
@@ -768,7 +924,16 @@ kmx_status kmx_index_info(const kmx_index* ix, uint64_t* n, uint32_t* sigma, uin
         if (ks) ks[i] = ix->ks[i];
         if (table_kinds) table_kinds[i] = ix->table_kinds[i];
     }
-    if (device_bytes) *device_bytes = ix->device_bytes;
+    if (device_bytes) *device_bytes = ix->device_bytes;          // per replica
+    return KMX_OK;
+}
+
+kmx_status kmx_index_devices(const kmx_index* ix, uint32_t* n_devices, int32_t* devices)
+{
+    if (!ix || !n_devices) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_devices: NULL argument");
+    *n_devices = uint32_t(ix->n_replicas());
+    if (devices)
+        for (size_t i = 0; i < ix->n_replicas(); ++i) devices[i] = const_cast<kmx_index*>(ix)->replica(i)->device;
     return KMX_OK;
 }
 
@@ -776,6 +941,10 @@ kmx_status kmx_index_extend_query_size_range(kmx_index* ix, uint32_t new_maximum
 {
     if (!ix || new_maximum == 0 || new_maximum > 65535 * 9u)
         return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_extend_query_size_range: bad argument");
+    for (kmx_index* peer : ix->peers) {
+        const kmx_status ps = kmx_index_extend_query_size_range(peer, new_maximum);
+        if (ps != KMX_OK) return ps;
+    }
     HIP_TRY(hipSetDevice(ix->device));
     HIP_TRY(hipDeviceSynchronize());
     std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, new_maximum);
@@ -786,6 +955,8 @@ kmx_status kmx_index_extend_query_size_range(kmx_index* ix, uint32_t new_maximum
     HIP_TRY(hipMemcpy(reinterpret_cast<char*>(ix->d_index) + offsetof(KmxIndexDev, plan), &d_plan, sizeof(d_plan), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(reinterpret_cast<char*>(ix->d_index) + offsetof(KmxIndexDev, range), &new_maximum, sizeof(new_maximum), hipMemcpyHostToDevice));
     ix->range = new_maximum;
+    ix->h_header.plan = d_plan;
+    ix->h_header.range = new_maximum;
     return KMX_OK;
 }
 
@@ -811,6 +982,7 @@ kmx_status kmx_debug_words(const kmx_index* ix, uint64_t* words16)
 kmx_status kmx_stats_enable(kmx_index* ix, int enable)
 {
     if (!ix) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_stats_enable: index is NULL");
+    for (kmx_index* peer : ix->peers) (void)kmx_stats_enable(peer, enable);
     std::lock_guard<std::mutex> lock(ix->stats.mu);
     ix->stats.enabled = enable != 0;
     return KMX_OK;
@@ -819,9 +991,19 @@ kmx_status kmx_stats_enable(kmx_index* ix, int enable)
 kmx_status kmx_stats_get(kmx_index* ix, kmx_kernel_stat* stats, uint32_t* n)
 {
     if (!ix || !stats || !n) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_stats_get: NULL argument");
-    std::lock_guard<std::mutex> lock(ix->stats.mu);
-    ix->stats.drain();
-    for (int i = 0; i < K_COUNT; ++i) stats[i] = kmx_kernel_stat{kKernelNames[i], ix->stats.launches[i], ix->stats.ms[i]};
+    {
+        std::lock_guard<std::mutex> lock(ix->stats.mu);
+        (void)hipSetDevice(ix->device);
+        ix->stats.drain();
+        for (int i = 0; i < K_COUNT; ++i) stats[i] = kmx_kernel_stat{kKernelNames[i], ix->stats.launches[i], ix->stats.ms[i]};
+    }
+    for (kmx_index* peer : ix->peers) {                       // every replica's launches add up
+        std::lock_guard<std::mutex> lock(peer->stats.mu);
+        (void)hipSetDevice(peer->device);
+        peer->stats.drain();
+        for (int i = 0; i < K_COUNT; ++i) { stats[i].launches += peer->stats.launches[i]; stats[i].total_ms += peer->stats.ms[i]; }
+    }
+    if (!ix->peers.empty()) (void)hipSetDevice(ix->device);
     *n = K_COUNT;
     return KMX_OK;
 }
@@ -829,13 +1011,13 @@ kmx_status kmx_stats_get(kmx_index* ix, kmx_kernel_stat* stats, uint32_t* n)
 kmx_status kmx_stats_reset(kmx_index* ix)
 {
     if (!ix) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_stats_reset: index is NULL");
+    for (kmx_index* peer : ix->peers) (void)kmx_stats_reset(peer);
     std::lock_guard<std::mutex> lock(ix->stats.mu);
+    (void)hipSetDevice(ix->device);
     ix->stats.drain();
     for (int i = 0; i < K_COUNT; ++i) { ix->stats.launches[i] = 0; ix->stats.ms[i] = 0; }
     return KMX_OK;
 }
-
-static kmx_status search_finish(kmx_result* r);
 
 kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, const void* d_qoff, uint64_t nq,
                                    uint32_t flags, void* stream, kmx_result** inout)
@@ -844,12 +1026,25 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     if (nq && (!d_qranks || !d_qoff)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: NULL query buffers");
     if (nq >= 0xFFFFFFFFull) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: at most 2^32-2 queries per batch");
     kmx_index* ix = const_cast<kmx_index*>(cix);
+    if (!ix->peers.empty() && nq) {
+        // several replicas: the one that lives where the queries are
+        hipPointerAttribute_t attr{};
+        if (hipPointerGetAttributes(&attr, d_qranks) != hipSuccess) { (void)hipGetLastError(); return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: d_qranks is not a device pointer"); }
+        kmx_index* pick = nullptr;
+        for (size_t i = 0; i < ix->n_replicas() && !pick; ++i)
+            if (ix->replica(i)->device == attr.device) pick = ix->replica(i);
+        if (!pick) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: the queries live on a device that holds no replica of this index");
+        ix = pick;
+    }
     HIP_TRY(hipSetDevice(ix->device));
     hipStream_t s = static_cast<hipStream_t>(stream);
     const uint8_t* qr = static_cast<const uint8_t*>(d_qranks);
     const uint64_t* qo = static_cast<const uint64_t*>(d_qoff);
 
     kmx_result* r = *inout;
+    if (r && !r->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: the result handle belongs to a multi-device search");
+    if (r && r->nq && r->device != ix->device && r->device_bytes())
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: the result handle holds buffers on another device");
     if (!r) { r = take_result(ix); *inout = r; }
     else if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }   // its buffers are about to be reused
     r->index = ix;
@@ -916,6 +1111,9 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     if (flags & KMX_SEARCH_ASYNC) {
         if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
         HIP_TRY(hipEventRecord(r->done, s));
+        r->pool = ix->pool;                                  // (a handle made for another index keeps its buffers, changes pools)
+        std::lock_guard<std::mutex> lock(ix->pool->mu);
+        ix->pool->pending.push_back(r);
         return KMX_OK;
     }
     return search_finish(r);
@@ -928,6 +1126,11 @@ static kmx_status search_finish(kmx_result* r)
     if (!r->ctx.pending) return KMX_OK;
     r->ctx.pending = false;
     kmx_index* ix = r->ctx.ix;
+    if (r->flags & KMX_SEARCH_ASYNC) {
+        std::lock_guard<std::mutex> lock(ix->pool->mu);
+        auto& pend = ix->pool->pending;
+        pend.erase(std::remove(pend.begin(), pend.end(), r), pend.end());
+    }
     const uint8_t* qr = r->ctx.qr;
     const uint64_t* qo = r->ctx.qo;
     hipStream_t s = r->ctx.s;
@@ -1047,6 +1250,43 @@ static kmx_status search_finish(kmx_result* r)
     return KMX_OK;
 }
 
+// host-buffer search of one replica: inputs to the device on the result's own stream, the device form behind them.
+// `wait`: return with the search complete; otherwise its second half stays pending (multi-device: every replica is
+// started before any is waited for).
+static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const uint64_t* qoff, uint64_t q0, uint64_t q1, uint32_t flags,
+                                  kmx_result** inout, bool wait)
+{
+    HIP_TRY(hipSetDevice(ix->device));
+    kmx_result* r = *inout ? *inout : take_result(ix);
+    *inout = r;
+    if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
+    if (!r->own_stream) HIP_TRY(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
+    const uint64_t nq = q1 - q0;
+    const uint64_t l0 = nq ? qoff[q0] : 0, n_letters = nq ? qoff[q1] - l0 : 0;
+    HIP_TRY(r->in_qranks.ensure(std::max<uint64_t>(n_letters, 1) + 16));
+    HIP_TRY(r->in_qoff.ensure((nq + 1) * 8));
+    if (n_letters) HIP_TRY(hipMemcpyAsync(r->in_qranks.p, qranks + l0, n_letters, hipMemcpyHostToDevice, r->own_stream));
+    if (nq) {
+        if (l0 == 0) {
+            HIP_TRY(hipMemcpyAsync(r->in_qoff.p, qoff + q0, (nq + 1) * 8, hipMemcpyHostToDevice, r->own_stream));
+        } else {
+            // a shard's offsets are rebased to its own letters
+            std::vector<uint64_t> local(nq + 1);
+            for (uint64_t i = 0; i <= nq; ++i) local[i] = qoff[q0 + i] - l0;
+            HIP_TRY(hipMemcpyAsync(r->in_qoff.p, local.data(), (nq + 1) * 8, hipMemcpyHostToDevice, r->own_stream));
+            HIP_TRY(hipStreamSynchronize(r->own_stream));           // `local` goes out of scope
+        }
+    }
+    const uint32_t f = wait ? (flags & ~KMX_SEARCH_ASYNC) : (flags | KMX_SEARCH_ASYNC);
+    kmx_status st = kmx_search_batch_device(ix, r->in_qranks.p, r->in_qoff.p, nq, f, r->own_stream, inout);
+    if (st != KMX_OK) return st;
+    if (wait) {
+        HIP_TRY(hipStreamSynchronize(r->own_stream));
+        r->quiesced = true;
+    }
+    return KMX_OK;
+}
+
 kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
                             uint32_t flags, kmx_result** out)
 {
@@ -1056,20 +1296,44 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     for (uint64_t i = 0; i < nq; ++i)
         if (qoff[i + 1] < qoff[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: qoff must be non-decreasing");
     kmx_index* ix = const_cast<kmx_index*>(cix);
-    std::lock_guard<std::mutex> lock(ix->host_call_mu);
-    HIP_TRY(hipSetDevice(ix->device));
-    kmx_result* r = *out ? *out : take_result(ix);
-    *out = r;
-    const uint64_t n_letters = nq ? qoff[nq] : 0;
-    HIP_TRY(r->in_qranks.ensure(std::max<uint64_t>(n_letters, 1)));
-    HIP_TRY(r->in_qoff.ensure((nq + 1) * 8));
-    if (n_letters) HIP_TRY(hipMemcpyAsync(r->in_qranks.p, qranks, n_letters, hipMemcpyHostToDevice, ix->stream));
-    if (nq) HIP_TRY(hipMemcpyAsync(r->in_qoff.p, qoff, (nq + 1) * 8, hipMemcpyHostToDevice, ix->stream));
-    kmx_status st = kmx_search_batch_device(ix, r->in_qranks.p, r->in_qoff.p, nq, flags & ~KMX_SEARCH_ASYNC, ix->stream, out);
-    if (st != KMX_OK) return st;
-    HIP_TRY(hipStreamSynchronize(ix->stream));
-    r->quiesced = true;
-    return KMX_OK;
+    const size_t W = ix->n_replicas();
+    if (W == 1) {
+        if (*out && !(*out)->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle belongs to a multi-device search");
+        return search_host_one(ix, qranks, qoff, 0, nq, flags, out, true);
+    }
+    // several replicas: replica r searches the contiguous range [nq*r/W, nq*(r+1)/W) on its own device and
+    // stream; all of them are started before the first is waited for.  The parent result presents the parts as one.
+    int caller_device = 0;
+    (void)hipGetDevice(&caller_device);
+    kmx_result* parent = *out;
+    if (parent && parent->parts.size() != W) {
+        if (!parent->parts.empty() || parent->device_bytes()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle was made by a search of another shape");
+    }
+    if (!parent) { parent = new kmx_result(); *out = parent; }
+    parent->index = ix;
+    parent->device = ix->device;
+    parent->flags = flags & ~KMX_SEARCH_ASYNC;
+    parent->nq = nq;
+    parent->host_valid = parent->host_masks_valid = false;
+    parent->parts.resize(W, nullptr);
+    parent->part_q0.assign(W + 1, 0);
+    for (size_t r = 0; r <= W; ++r) parent->part_q0[r] = nq / W * r + (nq % W) * r / W;   // == floor(nq * r / W) without the overflow
+    if (nq < 256 * W)                                   // a handful of queries: one device, one round trip (the other parts stay empty)
+        for (size_t r = 1; r <= W; ++r) parent->part_q0[r] = nq;
+    kmx_status st = KMX_OK;
+    for (size_t r = 0; r < W && st == KMX_OK; ++r)
+        st = search_host_one(ix->replica(r), qranks, qoff, parent->part_q0[r], parent->part_q0[r + 1], flags, &parent->parts[r], false);
+    parent->n_hits = parent->n_exact = parent->n_stitch = parent->n_prefix = parent->n_error = parent->n_none = parent->n_mask_words = 0;
+    for (size_t r = 0; r < W; ++r) {
+        kmx_result* p = parent->parts[r];
+        if (!p) continue;
+        const kmx_status fs = search_finish(p);
+        if (st == KMX_OK) st = fs;
+        parent->n_hits += p->n_hits; parent->n_exact += p->n_exact; parent->n_stitch += p->n_stitch; parent->n_prefix += p->n_prefix;
+        parent->n_error += p->n_error; parent->n_none += p->n_none;
+    }
+    (void)hipSetDevice(caller_device);
+    return st;
 }
 
 kmx_status kmx_result_counts(const kmx_result* r, uint64_t* nq, uint64_t* n_hits, uint64_t* n_exact, uint64_t* n_stitch,
@@ -1086,10 +1350,31 @@ kmx_status kmx_result_counts(const kmx_result* r, uint64_t* nq, uint64_t* n_hits
     return KMX_OK;
 }
 
+kmx_status kmx_result_parts(const kmx_result* r, uint32_t* n_parts)
+{
+    if (!r || !n_parts) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_parts: NULL argument");
+    *n_parts = r->parts.empty() ? 1u : uint32_t(r->parts.size());
+    return KMX_OK;
+}
+
+kmx_status kmx_result_part_view_device(const kmx_result* r, uint32_t part, int32_t* device, uint64_t* q_begin, uint64_t* q_end,
+                                       const uint64_t** d_hit_off, const uint32_t** d_positions, const uint8_t** d_status)
+{
+    if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_part_view_device: result is NULL");
+    const uint32_t n_parts = r->parts.empty() ? 1u : uint32_t(r->parts.size());
+    if (part >= n_parts) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_part_view_device: no such part");
+    const kmx_result* p = r->parts.empty() ? r : r->parts[part];
+    if (device) *device = p->device;
+    if (q_begin) *q_begin = r->parts.empty() ? 0 : r->part_q0[part];
+    if (q_end) *q_end = r->parts.empty() ? r->nq : r->part_q0[part + 1];
+    return kmx_result_view_device(p, d_hit_off, d_positions, d_status);
+}
+
 kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_off, const uint32_t** d_positions,
                                   const uint8_t** d_status)
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: result is NULL");
+    if (!r->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: the result spans several devices: use kmx_result_part_view_device");
     if (r->ctx.pending) { kmx_status fs = search_finish(const_cast<kmx_result*>(r)); if (fs != KMX_OK) return fs; }
     if (d_hit_off) *d_hit_off = r->hit_off.as<uint64_t>();
     if (d_positions) *d_positions = r->out.as<uint32_t>();
@@ -1102,6 +1387,46 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view: result is NULL");
     if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
+    if (!r->parts.empty() && !r->host_valid) {
+        // the parts of a multi-device result, concatenated in replica order: every device copies straight into its slice
+        // of the one host buffer (all links at once), the offsets are rebased on the host
+        const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
+        if (!r->h_hit_off.ensure((r->nq + 1) * 8) || !r->h_status.ensure(std::max<uint64_t>(r->nq, 1)) ||
+            !r->h_kinds.ensure(std::max<uint64_t>(r->nq, 1)) || !r->h_positions.ensure(std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
+            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_view: host allocation failed");
+        r->v_hit_off = r->h_hit_off.as<uint64_t>();
+        r->v_positions = r->h_positions.as<uint32_t>();
+        r->v_status = r->h_status.as<uint8_t>();
+        r->v_kinds = r->h_kinds.as<uint8_t>();
+        int caller_device = 0;
+        (void)hipGetDevice(&caller_device);
+        uint64_t h0 = 0;
+        r->v_hit_off[0] = 0;
+        for (size_t i = 0; i < r->parts.size(); ++i) {
+            kmx_result* p = r->parts[i];
+            const uint64_t q0 = r->part_q0[i], nqp = r->part_q0[i + 1] - q0;
+            HIP_TRY(hipSetDevice(p->device));
+            if (nqp) {
+                HIP_TRY(hipMemcpyAsync(r->v_hit_off + q0 + 1, p->hit_off.as<uint64_t>() + 1, nqp * 8, hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipMemcpyAsync(r->v_status + q0, p->status.p, nqp, hipMemcpyDeviceToHost, p->stream));
+                HIP_TRY(hipMemcpyAsync(r->v_kinds + q0, p->kind.p, nqp, hipMemcpyDeviceToHost, p->stream));
+            }
+            if (have_pos && p->n_hits) HIP_TRY(hipMemcpyAsync(r->v_positions + h0, p->out.p, p->n_hits * 4, hipMemcpyDeviceToHost, p->stream));
+            h0 += p->n_hits;
+        }
+        h0 = 0;
+        for (size_t i = 0; i < r->parts.size(); ++i) {
+            kmx_result* p = r->parts[i];
+            HIP_TRY(hipSetDevice(p->device));
+            HIP_TRY(hipStreamSynchronize(p->stream));
+            p->quiesced = true;
+            if (h0)
+                for (uint64_t q = r->part_q0[i] + 1; q <= r->part_q0[i + 1]; ++q) r->v_hit_off[q] += h0;
+            h0 += p->n_hits;
+        }
+        (void)hipSetDevice(caller_device);
+        r->host_valid = true;
+    }
     if (!r->host_valid) {
         HIP_TRY(hipSetDevice(r->device));
         const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
@@ -1153,6 +1478,31 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: result is NULL");
     if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
     if (!(r->flags & KMX_SEARCH_KEEP_MASKS)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: search ran without KMX_SEARCH_KEEP_MASKS");
+    if (!r->parts.empty() && !r->host_masks_valid) {
+        // per-part mask views, concatenated; a part's mask_base counts from its own first word, cand_src is an arena
+        // index and the same in every replica
+        uint64_t n_words = 0;
+        r->part_w0.assign(r->parts.size() + 1, 0);
+        for (size_t i = 0; i < r->parts.size(); ++i) { n_words += r->parts[i]->n_mask_words; r->part_w0[i + 1] = n_words; }
+        r->n_mask_words = n_words;
+        const uint64_t nq1 = std::max<uint64_t>(r->nq, 1);
+        if (!r->h_mask_base.ensure(nq1 * 8) || !r->h_cand_count.ensure(nq1 * 4) || !r->h_cand_src.ensure(nq1 * 8) ||
+            !r->h_mask_words.ensure(std::max<uint64_t>(n_words, 1) * 8))
+            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_masks: host allocation failed");
+        int caller_device = 0;
+        (void)hipGetDevice(&caller_device);
+        for (size_t i = 0; i < r->parts.size(); ++i) {
+            const uint64_t* mb; const uint64_t* mw; const uint32_t* cc; const uint64_t* cs;
+            const kmx_status st = kmx_result_masks(r->parts[i], &mb, &mw, &cc, &cs);
+            if (st != KMX_OK) { (void)hipSetDevice(caller_device); return st; }
+            const uint64_t q0 = r->part_q0[i], nqp = r->part_q0[i + 1] - q0, w0 = r->part_w0[i];
+            for (uint64_t q = 0; q < nqp; ++q) r->h_mask_base.as<uint64_t>()[q0 + q] = mb[q] + w0;
+            if (nqp) { memcpy(r->h_cand_count.as<uint32_t>() + q0, cc, nqp * 4); memcpy(r->h_cand_src.as<uint64_t>() + q0, cs, nqp * 8); }
+            if (r->parts[i]->n_mask_words) memcpy(r->h_mask_words.as<uint64_t>() + w0, mw, r->parts[i]->n_mask_words * 8);
+        }
+        (void)hipSetDevice(caller_device);
+        r->host_masks_valid = true;
+    }
     if (!r->host_masks_valid) {
         HIP_TRY(hipSetDevice(r->device));
         HIP_TRY(hipStreamSynchronize(r->stream));
@@ -1179,6 +1529,13 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
 void kmx_result_free(kmx_result* r)
 {
     if (!r) return;
+    if (!r->parts.empty()) {
+        for (kmx_result* p : r->parts) kmx_result_free(p);     // each part returns to its replica's pool
+        r->parts.clear();
+        r->release();
+        delete r;
+        return;
+    }
     if (r->ctx.pending) (void)search_finish(r);
     if (r->pool && r->device_bytes() <= kPoolMaxBytes) {
         if (!r->quiesced) {                                  // its buffers are about to serve another stream
@@ -1305,12 +1662,9 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
 {
     if (!path || !out) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: NULL argument");
     *out = nullptr;
-    kmx_options o{};
-    o.device = -1;
-    if (opts) {
-        if (opts->struct_size != sizeof(kmx_options)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: options.struct_size mismatch");
-        o = *opts;
-    }
+    kmx_options o;
+    if (!read_options(opts, o)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: options.struct_size mismatch");
+    if (o.n_devices > 1) o.device = o.devices[0];
     FILE* f = fopen(path, "rb");
     if (!f) return fail(KMX_ERR_INVALID_ARGUMENT, std::string("kmx_index_load: cannot open ") + path);
     struct Closer { FILE* f; ~Closer() { fclose(f); } } closer{f};
@@ -1353,10 +1707,47 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
             return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
     }
     if (mx.h != fh.checksum) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: checksum mismatch (corrupt image)");
+    // The checksum is not cryptographic and says nothing about an image that was WRITTEN wrong: check what the kernels
+    // index with.  A full slot table would make probe() spin for ever, an offset past the region reads out of bounds.
+    for (uint32_t i = 0; i < fh.n_ks; ++i) {
+        const kmx::ElemImage& im = images[i];
+        auto bad = [&](const char* what) { return fail(KMX_ERR_INVALID_ARGUMENT, std::string("kmx_index_load: corrupt contents (k = ") + std::to_string(im.k) + "): " + what); };
+        if (im.offs.empty() || im.offs.front() != 0 || im.offs.back() != im.npos) return bad("group boundaries do not span the positions");
+        for (size_t j = 1; j < im.offs.size(); ++j)
+            if (im.offs[j] < im.offs[j - 1]) return bad("group boundaries are not monotone");
+        const uint64_t last_start = fh.n - im.k;
+        for (uint64_t j = 0; j < im.npos; ++j)
+            if (im.positions[j] > last_start) return bad("a position lies outside the text");
+        if (im.table_kind == KMX_TABLE_OPEN) {
+            const uint64_t cap = uint64_t(1) << im.log2cap;
+            if (2 * uint64_t(im.ukeys.size()) > cap) return bad("the open-addressing table is more than half full");
+            for (size_t j = 0; j < im.ukeys.size(); ++j) {
+                if (im.ukeys[j] >= im.n_keys || (j && im.ukeys[j] <= im.ukeys[j - 1])) return bad("distinct keys are not strictly ascending inside the key space");
+                if (im.offs[j + 1] == im.offs[j]) return bad("a listed key owns no position");
+            }
+            uint64_t used = 0;
+            for (const KmxSlot& sl : im.slots) {
+                if (!sl.cnt) continue;
+                ++used;
+                if (sl.key >= im.n_keys || uint64_t(sl.off) + sl.cnt > im.region) return bad("a slot points outside the element's region");
+            }
+            if (used != im.ukeys.size()) return bad("occupied slots and distinct keys differ in number");
+        } else if (!im.atab.empty()) {
+            for (size_t j = 0; j < im.atab.size(); ++j) {
+                if ((im.atab[j] & ~31u) > im.region) return bad("an aligned-table entry points outside the element's region");
+                if (j && (im.atab[j] & ~31u) < (im.atab[j - 1] & ~31u)) return bad("the aligned table is not monotone");
+            }
+            if ((im.atab.front() & ~31u) < im.npos) return bad("the aligned copy overlaps the contiguous copy");
+        }
+    }
     kmx_status st = check_device();
     if (st != KMX_OK) return st;
     int device = o.device;
     if (device < 0) HIP_TRY(hipGetDevice(&device));
     HIP_TRY(hipSetDevice(device));
-    return install_images_impl(images, tail.data(), fh.n, fh.sigma, o.query_size_range ? o.query_size_range : fh.range, device, o, out, nullptr);
+    st = install_images_impl(images, tail.data(), fh.n, fh.sigma, o.query_size_range ? o.query_size_range : fh.range, device, o, out, nullptr);
+    if (st != KMX_OK) return st;
+    st = add_replicas(*out, o);
+    if (st != KMX_OK) { std::string keep = g_err; kmx_index_free(*out); *out = nullptr; g_err = keep; }
+    return st;
 }

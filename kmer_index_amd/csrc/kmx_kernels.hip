@@ -23,6 +23,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <atomic>
 
 #include "kmx_kernels.h"
 
@@ -1829,6 +1830,19 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_copy_back(QueryDesc d, uin
 // ---------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of the loaded code object: set it once per
+// (kernel, device), not once per process (an index may live on any device of the node, replicas on several).
+static void allow_big_lds(const void* fn, size_t bytes, int which)
+{
+    static std::atomic<uint64_t> done[2] = {{0}, {0}};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+    const uint64_t bit = uint64_t(1) << (dev & 63);
+    if (done[which].load(std::memory_order_acquire) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, int(bytes));   // idempotent: a race sets it twice
+    done[which].fetch_or(bit, std::memory_order_release);
+}
+
 static inline unsigned int blocks_for(uint64_t n, uint64_t per_block)
 {
     uint64_t b = (n + per_block - 1) / per_block;
@@ -2007,12 +2021,8 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc
 
 void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off, uint32_t* out)
 {
-    static bool attr_set = false;
     const size_t lds = size_t(KMX_PSORT_BLOCK_CAP) * 4;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_prefix_sort_block), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        attr_set = true;
-    }
+    allow_big_lds(reinterpret_cast<const void*>(k_prefix_sort_block), lds, 0);
     unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
     const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks
     hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(KMX_PSB_THREADS), lds, s, d, n_prefix, hit_off, out);
@@ -2225,12 +2235,8 @@ void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, 
 // second stage for buckets beyond the wave sort's capacity (call when max bucket > KMX_PSORT_CAP)
 void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_keys, uint32_t* d_positions)
 {
-    static bool attr_set = false;
     const size_t lds = size_t(KMX_PSORT_BLOCK_CAP) * 4;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort_block), hipFuncAttributeMaxDynamicSharedMemorySize, int(lds));
-        attr_set = true;
-    }
+    allow_big_lds(reinterpret_cast<const void*>(k_bucket_sort_block), lds, 1);
     const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_keys, 256 * 4);
     hipLaunchKernelGGL(k_bucket_sort_block, dim3(blocks ? blocks : 1), dim3(1024), lds, s, d_offs, n_keys, d_positions);
 }

@@ -11,6 +11,7 @@ import numpy as np
 from . import build as _build
 
 KMX_MAX_KS = 32
+KMX_MAX_DEVICES = 16
 KMX_N_KERNELS = 16
 TABLE_AUTO, TABLE_OPEN, TABLE_DENSE = 0, 1, 2
 SEARCH_DEFAULT, SEARCH_KEEP_MASKS, SEARCH_COUNT_ONLY, SEARCH_ASYNC = 0, 1, 2, 4
@@ -23,6 +24,7 @@ EXPORTS = [
     "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
+    "kmx_index_devices", "kmx_result_parts", "kmx_result_part_view_device",
 ]
 
 
@@ -35,7 +37,8 @@ class KmxError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_kind", C.c_uint32),
                 ("n_threads", C.c_uint32), ("query_size_range", C.c_uint32), ("keep_host_arena", C.c_uint32),
-                ("host_flatten", C.c_uint32), ("no_aligned_copy", C.c_uint32)]
+                ("host_flatten", C.c_uint32), ("no_aligned_copy", C.c_uint32),
+                ("n_devices", C.c_uint32), ("devices", C.c_int32 * KMX_MAX_DEVICES)]
 
 
 class KernelStat(C.Structure):
@@ -93,6 +96,12 @@ def lib():
         L.kmx_result_masks.restype = C.c_int
         L.kmx_result_masks.argtypes = [vp, P(vp), P(vp), P(vp), P(vp)]
         L.kmx_result_free.argtypes = [vp]
+        L.kmx_index_devices.restype = C.c_int
+        L.kmx_index_devices.argtypes = [vp, P(u32), vp]
+        L.kmx_result_parts.restype = C.c_int
+        L.kmx_result_parts.argtypes = [vp, P(u32)]
+        L.kmx_result_part_view_device.restype = C.c_int
+        L.kmx_result_part_view_device.argtypes = [vp, u32, P(C.c_int32), P(u64), P(u64), P(vp), P(vp), P(vp)]
         L.kmx_stats_enable.restype = C.c_int
         L.kmx_stats_enable.argtypes = [vp, C.c_int]
         L.kmx_stats_get.restype = C.c_int
@@ -107,6 +116,19 @@ def lib():
         L.kmx_version.restype = u32
         _lib = L
     return _lib
+
+
+def _set_devices(o, devices):
+    if devices is None:
+        o.n_devices = 0
+        return
+    devices = list(devices)
+    if not 1 <= len(devices) <= KMX_MAX_DEVICES:
+        raise ValueError("devices: between 1 and KMX_MAX_DEVICES ordinals")
+    o.n_devices = len(devices)
+    for i, d in enumerate(devices):
+        o.devices[i] = int(d)
+    o.device = int(devices[0])
 
 
 def _check(st):
@@ -150,6 +172,20 @@ class Result:
 
     def __init__(self):
         self._h = C.c_void_p()
+        self._index = None        # the Index of the last search: a pending (SEARCH_ASYNC) search reads it when it completes
+
+    def n_parts(self):
+        n = C.c_uint32()
+        _check(lib().kmx_result_parts(self._h, C.byref(n)))
+        return int(n.value)
+
+    def part_device_ptrs(self, part):
+        """(device ordinal, q_begin, q_end, d_hit_off, d_positions, d_status) of one part of a multi-device result;
+        hit_off is local to the part."""
+        dev, qb, qe = C.c_int32(), C.c_uint64(), C.c_uint64()
+        a, b, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().kmx_result_part_view_device(self._h, part, C.byref(dev), C.byref(qb), C.byref(qe), C.byref(a), C.byref(b), C.byref(s)))
+        return int(dev.value), int(qb.value), int(qe.value), a.value, b.value, s.value
 
     def counts(self):
         v = [C.c_uint64() for _ in range(6)]
@@ -201,6 +237,7 @@ class Result:
         if self._h:
             lib().kmx_result_free(self._h)
             self._h = C.c_void_p()
+        self._index = None
 
     def __del__(self):
         try:
@@ -213,7 +250,9 @@ class Index:
     """kmx_index handle: the flattened kmer_index<alphabet_t, uint32_t, ks...> resident in HBM."""
 
     def __init__(self, ranks, sigma, ks, table=TABLE_AUTO, device=-1, n_threads=0, keep_host_arena=False,
-                 query_size_range=0, host_flatten=False, aligned_copy=True):
+                 query_size_range=0, host_flatten=False, aligned_copy=True, devices=None):
+        """devices: None = one replica on `device` (KMX_DEVICES in the environment may widen it); a list of ordinals =
+        built on devices[0] and replicated onto the others (host-buffer searches then shard over the replicas)."""
         ranks = np.ascontiguousarray(ranks, np.uint8)
         ks = np.ascontiguousarray(ks, np.uint32)
         self.ks = ks.tolist()
@@ -228,18 +267,20 @@ class Index:
         o.keep_host_arena = int(keep_host_arena)
         o.host_flatten = int(host_flatten)
         o.no_aligned_copy = int(not aligned_copy)
+        _set_devices(o, devices)
         self._h = C.c_void_p()
         _check(lib().kmx_index_build(ranks.ctypes.data, ranks.size, self.sigma, ks.ctypes.data, ks.size,
                                      C.byref(o), C.byref(self._h)))
 
     @classmethod
-    def load(cls, path, device=-1, keep_host_arena=False):
+    def load(cls, path, device=-1, keep_host_arena=False, devices=None):
         """kmx_index_load: an index from an image written by save()."""
         self = cls.__new__(cls)
         o = Options()
         o.struct_size = C.sizeof(Options)
         o.device = device
         o.keep_host_arena = int(keep_host_arena)
+        _set_devices(o, devices)
         self._h = C.c_void_p()
         _check(lib().kmx_index_load(os.fsencode(path), C.byref(o), C.byref(self._h)))
         info = self.info()
@@ -257,6 +298,12 @@ class Index:
         return {"n": n.value, "sigma": sigma.value, "ks": ks[:nks.value].tolist(), "tables": tk[:nks.value].tolist(),
                 "device_bytes": dbytes.value}
 
+    def devices(self):
+        n = C.c_uint32()
+        d = (C.c_int32 * KMX_MAX_DEVICES)()
+        _check(lib().kmx_index_devices(self._h, C.byref(n), d))
+        return [int(d[i]) for i in range(n.value)]
+
     def extend_query_size_range(self, new_maximum):
         _check(lib().kmx_index_extend_query_size_range(self._h, new_maximum))
 
@@ -272,12 +319,14 @@ class Index:
         r = result or Result()
         _check(lib().kmx_search_batch(self._h, qranks.ctypes.data if qranks.size else None, qoff.ctypes.data,
                                       qoff.size - 1, flags, C.byref(r._h)))
+        r._index = self
         return r
 
     def search_device(self, d_qranks_ptr, d_qoff_ptr, nq, flags=SEARCH_DEFAULT, stream=0, result=None):
         """Device-buffer batch search (kmx_search_batch_device) on a caller-owned hipStream_t."""
         r = result or Result()
         _check(lib().kmx_search_batch_device(self._h, d_qranks_ptr, d_qoff_ptr, nq, flags, stream or None, C.byref(r._h)))
+        r._index = self
         return r
 
     def debug_words(self):

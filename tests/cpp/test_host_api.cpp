@@ -2,6 +2,7 @@
 // (test_main.cpp:21-69 — build single-k and multi-k indices, compare search(q).to_vector() with the
 // exact occurrence list for query sizes around k) compiled against include/kmer_index_amd/ and run
 // on the GPU.  Ground truth is a naive scan (the reference uses seqan3::fm_index, absent here).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -94,9 +95,35 @@ void run_test(std::size_t text_size, std::uint64_t seed)
             // zero-copy view: candidates filtered by the mask == to_vector()
             std::vector<std::uint32_t> filtered;
             for (std::size_t c = 0; c < batch[i].n_candidates(); ++c)
-                if (batch[i].should_use(c) && !batch[i].should_not_use(c)) filtered.push_back(batch[i].candidates()[c]);
+                if (batch[i].is_valid(c)) filtered.push_back(batch[i].candidates()[c]);
             CHECK(filtered == truth);
             CHECK(batch[i].bitmask().count_bits_equal_to(true) == truth.size());
+            // should_not_use / should_use are mutators (kmer_index_result.hpp:228-236): to_vector() follows the edited mask
+            if (batch[i].n_candidates() > 0)
+            {
+                auto edited = batch[i];
+                std::size_t c = 0;
+                while (c + 1 < edited.n_candidates() && !edited.is_valid(c)) ++c;
+                const bool was = edited.is_valid(c);
+                const std::uint32_t p = edited.candidates()[c];
+                edited.should_not_use(c);
+                auto without = truth;
+                if (was) without.erase(std::find(without.begin(), without.end(), p));
+                CHECK(edited.to_vector() == without && edited.size() == without.size() && !edited.is_valid(c));
+                edited.should_use(c);
+                auto with = without;
+                with.insert(std::lower_bound(with.begin(), with.end(), p), p);
+                CHECK(edited.to_vector() == with && edited.is_valid(c));
+                CHECK(batch[i].to_vector() == truth);                      // the original result is untouched
+            }
+        }
+        else
+        {
+            // a result that bypasses its mask has a 0-bit mask: the reference's set_0 / set_1 throw std::out_of_range
+            auto copy = batch[i];
+            bool threw = false;
+            try { copy.should_not_use(0); } catch (const std::out_of_range&) { threw = true; }
+            CHECK(threw);
         }
     }
 }
@@ -118,6 +145,21 @@ int main()
         threw = false;
         try { std::vector<dna4> q(text.begin(), text.begin() + 1); index.search(q); } catch (const std::invalid_argument&) { threw = true; }
         CHECK(threw);                                   // 4^12 > 1e7 buckets
+        // a batch keeps its good results when one query is bad
+        {
+            std::vector<std::vector<dna4>> qs;
+            qs.emplace_back(text.begin() + 5, text.begin() + 7);
+            qs.emplace_back(text.begin(), text.begin() + 1);             // sub-k fan-out
+            qs.emplace_back(text.begin() + 40, text.begin() + 53);
+            std::vector<std::uint8_t> st;
+            auto rs = index.search(qs, st);
+            CHECK(st.size() == 3 && st[0] == KMX_Q_OK && st[1] == KMX_Q_SUBK_FANOUT && st[2] == KMX_Q_OK);
+            CHECK(rs[0].to_vector() == naive(text, qs[0]) && rs[1].empty() && rs[2].to_vector() == naive(text, qs[2]));
+            bool caught = false;
+            try { (void)index.search(qs); }
+            catch (const decltype(index)::batch_query_error& e) { caught = e.query_index == 1 && e.results.size() == 3 && e.results[2].to_vector() == naive(text, qs[2]); }
+            CHECK(caught);
+        }
         std::vector<dna4> ok(text.begin() + 5, text.begin() + 7);
         CHECK(index.search(ok).to_vector() == naive(text, ok));
         CHECK(index.search(std::vector<dna4>(text.begin() + 50, text.begin() + 63)).size() >= 1);   // rvalue overload returns
@@ -141,6 +183,28 @@ int main()
         try { (void)kmer::kmer_index<dna4, std::uint32_t, 7, 10>::load("/tmp/kmx_host_api_test.img"); } catch (const std::invalid_argument&) { threw = true; }
         CHECK(threw);
         std::remove("/tmp/kmx_host_api_test.img");
+    }
+    // one index over several replicas (make_kmer_index's `devices`): a batch sharded over them == the single-device batch
+    {
+        auto text = generate_sequence<dna4>(21, 150000);
+        auto one = kmer::make_kmer_index<8, 10>(text);
+        auto many = kmer::make_kmer_index<8, 10>(text, 2, std::vector<int>{0, 0, 0});
+        CHECK(many.devices().size() == 3 && one.devices().size() == 1);
+        std::vector<std::vector<dna4>> qs;
+        for (std::size_t i = 0; i < 200; ++i)
+        {
+            const std::size_t len = 5 + (i * 7) % 26, s = (i * 7919) % (text.size() - len);
+            qs.emplace_back(text.begin() + s, text.begin() + s + len);
+        }
+        auto a = one.search(qs), b = many.search(qs);
+        CHECK(a.size() == b.size());
+        for (std::size_t i = 0; i < qs.size(); ++i)
+        {
+            CHECK(a[i].to_vector() == b[i].to_vector() && a[i].to_vector() == naive(text, qs[i]));
+            CHECK(a[i].bypasses_bitmask() == b[i].bypasses_bitmask());
+            if (!a[i].bypasses_bitmask()) CHECK(a[i].bitmask().words() == b[i].bitmask().words() && a[i].n_candidates() == b[i].n_candidates());
+        }
+        CHECK(many.search(qs[3]).to_vector() == naive(text, qs[3]));       // a batch of one lands on the first replica
     }
     if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
     std::printf("host api ok\n");

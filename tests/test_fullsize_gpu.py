@@ -73,8 +73,8 @@ def test_cfg2_dna4_k10_full(engine, orc):
 
 
 def test_cfg3_dna4_multi_k_mixed_full(engine, orc):
-    """configs[2]: multi-k {8,10,12} index over 1e8 bp, mixed lengths on the stitch path (2e6 queries materialised)."""
-    n, sigma, ks, nq = 100_000_000, 4, [8, 10, 12], 2_000_000
+    """configs[2]: multi-k {8,10,12} index over 1e8 bp, 1e7 mixed-length queries on the stitch path (BASELINE's size)."""
+    n, sigma, ks, nq = 100_000_000, 4, [8, 10, 12], 10_000_000
     text = synth.ranks(1003, n, sigma)
     q, off = synth.mixed_queries(2003, text, nq, [8, 10, 12, 20, 22, 24], sigma)
     idx = engine.Index(text, sigma, ks)

@@ -1,0 +1,144 @@
+"""The multi-device index of the C-ABI (kmx_options.devices): one build, replicated images, a host-buffer
+batch search sharded contiguously over the replicas in-process, ONE result whose views concatenate the shards in replica
+order — byte for byte what a single device returns.  Runs with two replicas on the box's one GPU (the replica list may
+name a device twice) and, when the box has them, with one replica per visible device."""
+import numpy as np
+import pytest
+
+from kmer_index_amd import synth
+from tests.helpers import make_queries
+
+pytestmark = pytest.mark.gpu
+
+
+def _device_sets():
+    import torch
+    n = torch.cuda.device_count()
+    sets = [[0, 0], [0, 0, 0]]
+    if n >= 2:
+        sets.append(list(range(min(n, 8))))
+    return sets
+
+
+def _same(a, b):
+    return all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("table", ["auto", "open"])
+def test_n_replicas_return_the_single_device_result_byte_for_byte(engine, table):
+    text = synth.ranks(1003, 400_000, 4)
+    ks = [8, 10, 12]
+    q, off = make_queries(text, 4, [3, 6, 8, 9, 10, 12, 13, 20, 22, 24, 31, 36], 400, seed=91)
+    tk = engine.TABLE_OPEN if table == "open" else engine.TABLE_AUTO
+    one = engine.Index(text, 4, ks, table=tk, device=0, keep_host_arena=True)
+    assert one.devices() == [0]
+    r1 = one.search(q, off, flags=engine.SEARCH_KEEP_MASKS)
+    want = r1.host()
+    base1, words1, cnt1, src1 = r1.masks()
+    c1 = r1.counts()
+    assert r1.n_parts() == 1
+    for devs in _device_sets():
+        many = engine.Index(text, 4, ks, table=tk, devices=devs, keep_host_arena=True)
+        assert many.devices() == devs and many.info()["device_bytes"] == one.info()["device_bytes"]
+        rn = many.search(q, off, flags=engine.SEARCH_KEEP_MASKS)
+        assert rn.n_parts() == len(devs) and rn.counts() == c1
+        got = rn.host()
+        assert _same(got, want), devs
+        # the zero-copy view: candidates (arena index is replica-independent) + mask words per STITCH query
+        basen, wordsn, cntn, srcn = rn.masks()
+        import ctypes as C
+        st = np.nonzero(want[3] == engine.KIND_STITCH)[0]
+        assert st.size > 100
+        assert np.array_equal(cntn[st], cnt1[st]) and np.array_equal(srcn[st], src1[st])
+        w1 = np.ctypeslib.as_array(C.cast(words1, C.POINTER(C.c_uint64)), shape=(int(base1[st].max()) + int(cnt1[st].max()) // 64 + 2,))
+        wn = np.ctypeslib.as_array(C.cast(wordsn, C.POINTER(C.c_uint64)), shape=(int(basen[st].max()) + int(cntn[st].max()) // 64 + 2,))
+        for i in st[:300]:
+            nw = int(cnt1[i]) // 64 + 1
+            assert np.array_equal(w1[int(base1[i]):int(base1[i]) + nw], wn[int(basen[i]):int(basen[i]) + nw])
+        # per-part device views: part p holds queries [q_begin, q_end) with part-local offsets
+        import torch
+        covered = 0
+        for p in range(rn.n_parts()):
+            dev, qb, qe, d_off, d_pos, d_st = rn.part_device_ptrs(p)
+            assert dev == devs[p] and qb == covered
+            covered = qe
+        assert covered == off.size - 1
+        with pytest.raises(engine.KmxError):
+            rn.device_ptrs()
+        # the handle is reusable for the next batch, also a smaller one; count-only works over parts
+        half = (off.size - 1) // 3
+        rn2 = many.search(q[:int(off[half])], off[:half + 1], result=rn)
+        h2, p2, s2, k2 = rn2.host()
+        assert np.array_equal(h2, want[0][:half + 1]) and np.array_equal(p2, want[1][:int(want[0][half])])
+        rc = many.search(q, off, flags=engine.SEARCH_COUNT_ONLY)
+        assert np.array_equal(rc.host()[0], want[0])
+        rc.close()
+        rn.close()
+        many.close()
+    r1.close()
+    one.close()
+
+
+def test_fewer_queries_than_replicas_and_empty_batches(engine):
+    text = synth.ranks(5, 50_000, 4)
+    many = engine.Index(text, 4, [6], devices=[0, 0, 0])
+    one = engine.Index(text, 4, [6], device=0)
+    for nq in (0, 1, 2, 4):
+        q, off = synth.uniform_queries(17, nq, 6, 4)
+        a, b = many.search(q, off), one.search(q, off)
+        assert _same(a.host(), b.host()) and a.counts() == b.counts()
+        a.close(); b.close()
+    many.close(); one.close()
+
+
+def test_device_form_on_a_replicated_index_uses_the_replica_where_the_queries_live(engine):
+    import torch
+    text = synth.ranks(1002, 300_000, 4)
+    idx = engine.Index(text, 4, [10], devices=[0, 0])
+    q, off = synth.uniform_queries(2002, 30_000, 10, 4)
+    d_q = torch.from_numpy(q).to("cuda:0")
+    d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+    r = idx.search_device(d_q.data_ptr(), d_off.data_ptr(), off.size - 1)
+    ref = engine.Index(text, 4, [10], device=0).search(q, off)
+    assert _same(r.host(), ref.host())
+    r.close(); ref.close(); idx.close()
+
+
+def test_replicated_image_loads_from_disk_and_env_var_widens_a_plain_build(engine, tmp_path, monkeypatch):
+    text = synth.ranks(8, 120_000, 5)
+    q, off = make_queries(text, 5, [4, 7, 9, 14, 18], 200, seed=3)
+    one = engine.Index(text, 5, [7, 9], device=0)
+    want = one.search(q, off).host()
+    p = str(tmp_path / "img.kmx")
+    one.save(p)
+    loaded = engine.Index.load(p, devices=[0, 0])
+    assert loaded.devices() == [0, 0] and _same(loaded.search(q, off).host(), want)
+    loaded.close()
+    monkeypatch.setenv("KMX_DEVICES", "0,0,0")           # what a make_kmer_index caller sets to use every GPU: "all"
+    env = engine.Index(text, 5, [7, 9])
+    assert env.devices() == [0, 0, 0] and _same(env.search(q, off).host(), want)
+    env.close()
+    monkeypatch.setenv("KMX_DEVICES", "all")
+    env = engine.Index(text, 5, [7, 9])
+    import torch
+    assert env.devices() == list(range(torch.cuda.device_count())) and _same(env.search(q, off).host(), want)
+    env.close()
+    one.close()
+
+
+def test_index_freed_before_a_pending_async_result(engine):
+    """a KMX_SEARCH_ASYNC search left pending on a result whose index is closed first — kmx_index_free
+    completes it, so touching the result afterwards neither launches kernels on freed memory nor loses the hits."""
+    import torch
+    text = synth.ranks(1002, 2_000_000, 4)
+    q, off = synth.uniform_queries(2002, 400_000, 10, 4)
+    d_q = torch.from_numpy(q).to("cuda:0")
+    d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+    idx = engine.Index(text, 4, [10], device=0)
+    want = idx.search(q, off).host()
+    res = engine.Result()
+    idx.search_device(d_q.data_ptr(), d_off.data_ptr(), off.size - 1, flags=engine.SEARCH_ASYNC, result=res)   # first batch: the fill is NOT speculative
+    idx.close()                                           # completes the pending half (validate / fill) before releasing the image
+    assert res.counts()["n_hits"] == want[1].size
+    assert _same(res.host(), want)
+    res.close()
