@@ -315,10 +315,26 @@ kmx_status check_device()
 
 } // namespace
 
+// Cells (KmxElemDev::cnt8) for a dense element with short buckets: log2 of the cell size in positions, or 0 for "no cells".
+// A cell must hold nearly every group — for i.i.d. text the sizes are Poisson(c) with c = npos / sigma^k, and a cell of
+// 8 / 16 / 32 positions leaves < 0.1 % of the keys out up to c = 2 / 6 / 24 — and the cells must not dwarf the index.
+static uint32_t cell_shift_for(uint32_t table_kind, uint64_t n_keys, uint64_t npos, uint64_t region, const kmx_options& o)
+{
+    if (table_kind != KMX_TABLE_DENSE || o.no_aligned_copy || region > npos) return 0;     // (long buckets have the aligned copy)
+    if (const char* e = getenv("KMX_CELLS")) { if (!atoi(e)) return 0; }
+    const double c = double(npos) / double(n_keys);
+    const uint32_t shift = c <= 2.0 ? 3u : c <= 6.0 ? 4u : c <= 24.0 ? 5u : 0u;
+    if (!shift) return 0;
+    if ((n_keys << shift) > 8 * npos) return 0;               // at most 8x the contiguous copy
+    return shift;
+}
+static inline uint64_t up32_elems(uint64_t v) { return (v + 31) & ~uint64_t(31); }
+
 // Uploads flattened element images and everything around them (tail, planner table, header).
 // Shared by kmx_index_build (images fresh from the flatten) and kmx_index_load (images from a file).
 static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const uint8_t* tail_kmax, uint64_t n, uint32_t sigma,
-                                 uint32_t range, int device, const kmx_options& o, kmx_index** out, void* prebuilt_arena)
+                                 uint32_t range, int device, const kmx_options& o, kmx_index** out, void* prebuilt_arena,
+                                 uint64_t prebuilt_arena_elems = 0)
 {
     auto* ix = new kmx_index();
     ix->device = device;
@@ -353,6 +369,22 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         if (im.region > im.npos) arena_elems = (arena_elems + 31) & ~uint64_t(31);   // an aligned copy needs a line-aligned base
         arena_elems += im.region;
     }
+    // cells of the dense elements with short buckets follow the elements' regions (derived data: not in the image)
+    std::vector<uint32_t> cell_shift(n_ks, 0);
+    std::vector<uint64_t> cell_base(n_ks, 0);
+    for (uint32_t i = 0; i < n_ks; ++i) {
+        const auto& im = images[i];
+        cell_shift[i] = cell_shift_for(im.table_kind, im.n_keys, im.npos, im.region, o);
+        if (cell_shift[i] && (up32_elems(arena_elems) + (im.n_keys << cell_shift[i]) + 65536) * 4 >= (uint64_t(1) << 32)) cell_shift[i] = 0;   // keep 32-bit arena offsets
+        if (!cell_shift[i]) continue;
+        arena_elems = up32_elems(arena_elems);
+        cell_base[i] = arena_elems;
+        arena_elems += im.n_keys << cell_shift[i];
+    }
+    if (prebuilt_arena && prebuilt_arena_elems < arena_elems) {   // (cannot happen: both sides size it with cell_shift_for)
+        fail(KMX_ERR_INVALID_ARGUMENT, "internal: the prebuilt arena is smaller than the index layout");
+        return bail(KMX_ERR_INVALID_ARGUMENT);
+    }
     {
         void* p = prebuilt_arena;                             // device-built elements already sit in it
         if (!p) {
@@ -376,7 +408,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         void* p = nullptr;
         if (hipMalloc(&p, 16 * 8) == hipSuccess) { (void)hipMemset(p, 0, 16 * 8); ix->allocs.push_back(p); h.dbg = static_cast<unsigned long long*>(p); ix->d_dbg = h.dbg; }
     }
-    if (o.keep_host_arena) ix->host_arena.reserve(arena_elems);
+    if (o.keep_host_arena) ix->host_arena.assign(arena_elems, 0);          // the mirror has the arena's layout, padding included
     uint64_t base = 0;
     for (uint32_t i = 0; i < n_ks; ++i) {
         auto& im = images[i];
@@ -390,17 +422,13 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
                                   (im.d_atab_prebuilt || (im.table_kind == KMX_TABLE_DENSE && !im.atab.empty())) ? size_t(im.n_keys + 1) : size_t(0)});
         if (im.positions_on_device) {
             if (o.keep_host_arena) {
-                ix->host_arena.resize(base + im.region);
                 hipError_t e = hipMemcpy(ix->host_arena.data() + base, h.arena + base, im.region * 4, hipMemcpyDeviceToHost);
                 if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena download: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
             }
         } else {
             hipError_t e = hipMemcpy(const_cast<uint32_t*>(h.arena) + base, im.positions.data(), im.region * 4, hipMemcpyHostToDevice);
             if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena upload: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
-            if (o.keep_host_arena) {
-                ix->host_arena.resize(base, 0);
-                ix->host_arena.insert(ix->host_arena.end(), im.positions.begin(), im.positions.begin() + im.region);
-            }
+            if (o.keep_host_arena) std::copy(im.positions.begin(), im.positions.begin() + im.region, ix->host_arena.begin() + base);
         }
         if (im.d_ukeys_prebuilt) {                              // open table built on the device
             const uint64_t nu = im.n_ukeys_prebuilt, cap = uint64_t(1) << im.log2cap;
@@ -443,6 +471,28 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
                 if (le != hipSuccess) { fail(KMX_ERR_HIP, std::string("key directory: ") + hipGetErrorString(le)); return bail(KMX_ERR_HIP); }
             } else {
                 (void)hipGetLastError();                            // no directory: the searches run over the whole key array
+            }
+        }
+        el.cnt8 = nullptr; el.cell_base = 0; el.cell_shift = 0; el.reserved0 = 0;
+        if (cell_shift[i]) {
+            void* p = nullptr;
+            hipError_t ce = hipMalloc(&p, im.n_keys + 64);                 // + 64: the lookup reads the aligned 16 bytes around an entry
+            if (ce == hipSuccess) {
+                ix->allocs.push_back(p);
+                ix->device_bytes += im.n_keys;
+                (void)hipMemset(p, 0, im.n_keys + 64);
+                kmx::launch_build_cells(nullptr, el.offs, h.arena + base, im.n_keys, cell_shift[i], const_cast<uint32_t*>(h.arena) + cell_base[i],
+                                        static_cast<uint8_t*>(p));
+                ce = hipGetLastError();
+                if (ce == hipSuccess) ce = hipDeviceSynchronize();
+            }
+            if (ce != hipSuccess) { fail(ce == hipErrorOutOfMemory ? KMX_ERR_OUT_OF_MEMORY : KMX_ERR_HIP, std::string("cells: ") + hipGetErrorString(ce)); return bail(KMX_ERR_HIP); }
+            el.cnt8 = static_cast<const uint8_t*>(p);
+            el.cell_base = cell_base[i];
+            el.cell_shift = cell_shift[i];
+            if (o.keep_host_arena) {                                       // candidate runs of STITCH queries may lie in cells
+                ce = hipMemcpy(ix->host_arena.data() + cell_base[i], h.arena + cell_base[i], (im.n_keys << cell_shift[i]) * 4, hipMemcpyDeviceToHost);
+                if (ce != hipSuccess) { fail(KMX_ERR_HIP, std::string("cells download: ") + hipGetErrorString(ce)); return bail(KMX_ERR_HIP); }
             }
         }
         base += im.region;
@@ -519,6 +569,8 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
         de.ukeys = static_cast<const uint64_t*>(p);
         if (!clone(se.dir, se.dir ? (size_t(se.n_dir) + 1) * 4 : 0, 64, &p)) return bail(st);
         de.dir = static_cast<const uint32_t*>(p);
+        if (!clone(se.cnt8, se.cnt8 ? size_t(se.n_keys) : 0, 64, &p)) return bail(st);
+        de.cnt8 = static_cast<const uint8_t*>(p);
     }
     if (!clone(nullptr, 0, 0, &p)) return bail(st);
     {
@@ -800,6 +852,11 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         bases[i] = arena_elems;
         arena_elems += images[i].region;
     }
+    for (uint32_t i = 0; i < n_ks; ++i) {                            // room for the cells install_images_impl derives (same rule there)
+        uint32_t cs = cell_shift_for(images[i].table_kind, images[i].n_keys, images[i].npos, images[i].region, o);
+        if (cs && (up32(arena_elems) + (images[i].n_keys << cs) + 65536) * 4 >= (uint64_t(1) << 32)) cs = 0;
+        if (cs) arena_elems = up32(arena_elems) + (images[i].n_keys << cs);
+    }
     {
         hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
         if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); }
@@ -875,7 +932,7 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         }
     }
 
-    st = install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena);
+    st = install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena, arena_elems);
     if (st != KMX_OK) return st;
     st = add_replicas(*out, o);
     if (st != KMX_OK) { std::string keep = g_err; kmx_index_free(*out); *out = nullptr; g_err = keep; }

@@ -30,6 +30,9 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
 uint64_t scan_blocks(uint64_t n);
 void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, uint32_t shift, uint32_t n_dir, uint32_t* d_dir);
+// cells of a dense element (KmxElemDev::cnt8): d_region = the element's contiguous copy, d_cells = cell 0
+void launch_build_cells(hipStream_t s, const uint32_t* d_offs, const uint32_t* d_region, uint64_t n_keys, uint32_t cell_shift,
+                        uint32_t* d_cells, uint8_t* d_cnt8);
 
 // kmx_build_sort.hip — device construction of an element with a key space beyond the histogram path:
 // positions (grouped by hash, ascending inside a group) into d_positions[n - k + 1], tables into new allocations

@@ -100,6 +100,10 @@ __device__ __forceinline__ Run probe(const KmxElemDev* __restrict__ el, uint64_t
 {
     Run r;
     if (el->table_kind == KMX_TABLE_DENSE) {
+        if (el->cnt8) {                                       // short buckets: one byte says how much of the key's cell is in use
+            const uint32_t c = as_global(el->cnt8)[h];
+            if (c != 255u) { r.src = el->cell_base + (h << el->cell_shift); r.cnt = c; return r; }
+        }
         if (el->atab) {                                       // the line-aligned copy of the bucket
             const KMX_GLOBAL uint32_t* atab = as_global(el->atab);
             const uint32_t e0 = atab[h], e1 = atab[h + 1];
@@ -298,7 +302,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             const char* addr = reinterpret_cast<const char*>(dummy);
             if (done[it] && ok) {
                 if (el->table_kind == KMX_TABLE_DENSE) {
-                    addr = reinterpret_cast<const char*>((el->atab ? el->atab : el->offs) + acc);
+                    addr = el->cnt8 ? reinterpret_cast<const char*>(el->cnt8 + (acc & ~uint64_t(15)))    // the aligned 16 bytes holding cnt8[h]
+                                    : reinterpret_cast<const char*>((el->atab ? el->atab : el->offs) + acc);
                 } else {
                     addr = reinterpret_cast<const char*>(el->slots + slot_hash_dev(acc, el->log2cap));
                 }
@@ -319,7 +324,18 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             if (!rok[it]) {
                 status = KMX_Q_BAD_RANK;
             } else if (el->table_kind == KMX_TABLE_DENSE) {
-                if (el->atab) { src = el->arena_base + (pr[it][0] & ~31u); cnt = atab_count(pr[it][0], pr[it][1]); }
+                if (el->cnt8) {
+                    const uint32_t b = uint32_t(hs[it]) & 15u;
+                    const uint32_t wsel = (b >> 2) == 0 ? pr[it][0] : (b >> 2) == 1 ? pr[it][1] : (b >> 2) == 2 ? pr[it][2] : pr[it][3];
+                    const uint32_t c = (wsel >> ((b & 3u) * 8u)) & 0xFFu;
+                    if (c != 255u) { src = el->cell_base + (hs[it] << el->cell_shift); cnt = c; }
+                    else {                                    // (rare) the group is longer than a cell: the contiguous copy
+                        const KMX_GLOBAL uint32_t* offs = as_global(el->offs);
+                        const uint32_t a = offs[hs[it]], b = offs[hs[it] + 1];
+                        src = el->arena_base + a; cnt = b - a;
+                    }
+                }
+                else if (el->atab) { src = el->arena_base + (pr[it][0] & ~31u); cnt = atab_count(pr[it][0], pr[it][1]); }
                 else { src = el->arena_base + pr[it][0]; cnt = pr[it][1] - pr[it][0]; }
             } else {
                 // linear probing continues from the prefetched slot (at(hash), :76-84)
@@ -2225,6 +2241,28 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_build_dir(const uint64_t* __restr
     const uint64_t j = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
     if (j > n_dir) return;
     dir[j] = j == n_dir ? uint32_t(n_ukeys) : uint32_t(lower_bound_dev<uint64_t>(ukeys, n_ukeys, j << shift));
+}
+
+// cells: slot j of key h <- the j-th position of the key's group (0 beyond its size, and for a key whose group does not fit)
+__global__ __launch_bounds__(KMX_BLOCK) void k_build_cells(const uint32_t* __restrict__ offs, const uint32_t* __restrict__ region,
+                                                           uint64_t n_keys, uint32_t cell_shift, uint32_t* __restrict__ cells,
+                                                           uint8_t* __restrict__ cnt8)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    const uint64_t h = i >> cell_shift;
+    if (h >= n_keys) return;
+    const uint32_t j = uint32_t(i) & ((1u << cell_shift) - 1u);
+    const uint32_t lo = offs[h], c = offs[h + 1] - lo;
+    const bool fits = c <= (1u << cell_shift);
+    cells[i] = (fits && j < c) ? region[lo + j] : 0u;
+    if (j == 0) cnt8[h] = fits ? uint8_t(c) : uint8_t(255);
+}
+
+void launch_build_cells(hipStream_t s, const uint32_t* d_offs, const uint32_t* d_region, uint64_t n_keys, uint32_t cell_shift,
+                        uint32_t* d_cells, uint8_t* d_cnt8)
+{
+    hipLaunchKernelGGL(k_build_cells, dim3(blocks_for(n_keys << cell_shift, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_offs, d_region, n_keys,
+                       cell_shift, d_cells, d_cnt8);
 }
 
 void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, uint32_t shift, uint32_t n_dir, uint32_t* d_dir)

@@ -47,6 +47,17 @@ struct KmxElemDev {
                            // directory cell.  Derived from ukeys when the index is installed; not part of the image.
     uint32_t dir_shift;
     uint32_t n_dir;
+    // dense tables with SHORT buckets (a handful of positions per key: DNA5 k = 10 on 1e8 bp, protein k = 5): a third
+    // layout of the groups, "cells" — key h owns the fixed-size, line-aligned cell [cell_base + (h << cell_shift), ... + 2^cell_shift)
+    // of the arena holding its positions (ascending, zero padded), and cnt8[h] its size, 255 for a key whose group does not
+    // fit a cell (those are served from offs / the contiguous copy as before).  An exact lookup then costs ONE byte out of a
+    // table of sigma^k bytes (L2 / Infinity-Cache resident) and its hit list ONE aligned line of the arena, where the
+    // contiguous copy costs two table entries out of a 4-byte-per-key table and a run that straddles lines 1.3 times on average.
+    // Derived from offs and the contiguous copy when the index is installed; not part of the image.  NULL: no cells.
+    const uint8_t* cnt8;
+    uint64_t cell_base;    // arena index of cell 0 (a multiple of 32)
+    uint32_t cell_shift;   // log2 of the cell size in positions: 3, 4 or 5 (32-, 64- or 128-byte cells)
+    uint32_t reserved0;
 };
 
 // Planner entry for one query length m — what kmer_index::search consults at

@@ -50,6 +50,18 @@ def _worker(rank, world, port, q):
                                               torch.zeros(0, dtype=torch.int32), dst=0)
         if rank == 0:
             assert e_off.numel() == 1 + 2 * (world - 1) and e_pos.numel() == 0
+        # one HitGather over several batches (bench.py's gather leg rotates two result handles through it): the kept
+        # buffers serve a smaller and then a larger batch, every gathered array is exact each time
+        gat = kdist.HitGather(dst=0)
+        for lo, hi in ((0, 400), (400, 1001), (100, 130)):
+            sq, so = qranks[int(qoff[lo]):int(qoff[hi])], (qoff[lo:hi + 1] - qoff[lo]).astype(np.uint64)
+            mq, mo = kdist.shard_queries(sq, so, rank, world)
+            ho, po, _, _ = oidx.search_batch(mq, mo)
+            go, gp = gat.gather(torch.from_numpy(ho.astype(np.int64)), torch.from_numpy(po.view(np.int32).copy()))
+            if rank == 0:
+                fo, fp, _, _ = oidx.search_batch(sq, so)
+                assert np.array_equal(go.numpy().astype(np.uint64), fo) and np.array_equal(gp.numpy().view(np.uint32), fp), (lo, hi)
+                assert sum(gat.last_bytes_per_peer) == 8 * (hi - lo - (len(mo) - 1)) + 4 * (fp.size - po.size)
         if rank == 0:
             f_off, f_pos, _, _ = oidx.search_batch(qranks, qoff)
             ok = (np.array_equal(g_off.numpy().astype(np.uint64), f_off) and np.array_equal(g_pos.numpy().view(np.uint32), f_pos)
