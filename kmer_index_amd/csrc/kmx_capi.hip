@@ -102,11 +102,11 @@ struct HostBuf {
 
 enum KernelId {
     K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK,
-    K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_COUNT
+    K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_lookup", "k_scan", "k_partition", "k_fill", "k_validate", "k_compact",
-    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block"};
+    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block", "k_small"};
 
 struct Stats {
     bool enabled = false;
@@ -213,6 +213,10 @@ struct kmx_result {
     // host mirrors
     HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src, h_small;
     uint64_t* v_hit_off = nullptr; uint32_t* v_positions = nullptr; uint8_t* v_status = nullptr; uint8_t* v_kinds = nullptr;   // the current host view
+    const uint64_t* m_base = nullptr; const uint64_t* m_words = nullptr; const uint32_t* m_ccnt = nullptr; const uint64_t* m_csrc = nullptr;   // ... and mask view
+    // the latency path (k_small): queries in, complete result out through one page-locked block the kernel reads and writes
+    HostBuf mailbox;
+    bool small_valid = false;              // the result of the last search lives in the mailbox only (no device buffers were written)
     bool host_valid = false, host_masks_valid = false;
     bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
     std::shared_ptr<ResultPool> pool;      // where kmx_result_free parks this result (set by the search that made it)
@@ -241,7 +245,7 @@ struct kmx_result {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
                           &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
             b->release();
-        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small})
+        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox})
             b->release();
         if (h_ctr) (void)hipHostFree(h_ctr);
         h_ctr = nullptr;
@@ -1112,6 +1116,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     r->nq = nq;
     r->n_hits = r->n_exact = r->n_stitch = r->n_prefix = r->n_error = r->n_none = r->n_mask_words = 0;
     r->host_valid = r->host_masks_valid = false;
+    r->small_valid = false;
     r->quiesced = false;
     if (!r->h_ctr) HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&r->h_ctr), KMX_CTR_COUNT * sizeof(unsigned long long), hipHostMallocDefault));
     HIP_TRY(r->hit_off.ensure((nq + 1) * 8));
@@ -1320,6 +1325,42 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
     if (!r->own_stream) HIP_TRY(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     const uint64_t nq = q1 - q0;
     const uint64_t l0 = nq ? qoff[q0] : 0, n_letters = nq ? qoff[q1] - l0 : 0;
+    // A handful of queries (kmer_index::search(query) is a batch of one): one launch that reads the queries from and
+    // writes the whole result to a page-locked block — no copies, no counter read-back, one wait.
+    static const bool no_small = getenv("KMX_NO_SMALL") != nullptr;
+    if (nq && nq <= KMX_SMALL_NQ && (nq + 1) * 8 + n_letters <= KMX_SMALL_IN_BYTES && !(flags & KMX_SEARCH_COUNT_ONLY) && !no_small &&
+        r->mailbox.ensure_pinned(KMX_SMALL_BYTES)) {
+        unsigned char* mb = r->mailbox.as<unsigned char>();
+        uint64_t* in_off = reinterpret_cast<uint64_t*>(mb);
+        for (uint64_t i = 0; i <= nq; ++i) in_off[i] = qoff[q0 + i] - l0;
+        if (n_letters) memcpy(mb + (nq + 1) * 8, qranks + l0, n_letters);
+        KmxSmallHeader* hdr = reinterpret_cast<KmxSmallHeader*>(mb + KMX_SMALL_OFF_HEADER);
+        hdr->fallback = 2;                                        // (overwritten by the kernel)
+        (void)hipGetLastError();
+        timed(ix, K_SMALL, r->own_stream, [&] { kmx::launch_small(r->own_stream, ix->d_index, ix->d_arena, mb, uint32_t(nq), uint32_t(n_letters), flags); });
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(r->own_stream));
+        if (hdr->fallback == 0) {
+            r->index = ix; r->device = ix->device; r->stream = r->own_stream; r->flags = flags & ~KMX_SEARCH_ASYNC;
+            r->nq = nq; r->n_hits = hdr->n_hits; r->n_mask_words = hdr->n_mask_words;
+            r->n_stitch = hdr->n_stitch; r->n_prefix = hdr->n_prefix; r->n_error = hdr->n_error; r->n_none = hdr->n_none;
+            r->n_exact = nq - r->n_stitch - r->n_prefix - r->n_error - r->n_none;
+            r->v_hit_off = reinterpret_cast<uint64_t*>(mb + KMX_SMALL_OFF_HITOFF);
+            r->v_positions = reinterpret_cast<uint32_t*>(mb + KMX_SMALL_OFF_POS);
+            r->v_status = mb + KMX_SMALL_OFF_STATUS;
+            r->v_kinds = mb + KMX_SMALL_OFF_KINDS;
+            r->m_base = reinterpret_cast<const uint64_t*>(mb + KMX_SMALL_OFF_MBASE);
+            r->m_words = reinterpret_cast<const uint64_t*>(mb + KMX_SMALL_OFF_WORDS);
+            r->m_ccnt = reinterpret_cast<const uint32_t*>(mb + KMX_SMALL_OFF_CCNT);
+            r->m_csrc = reinterpret_cast<const uint64_t*>(mb + KMX_SMALL_OFF_CSRC);
+            r->host_valid = r->host_masks_valid = true;
+            r->small_valid = true;
+            r->quiesced = true;
+            r->last_had_stitch = false;
+            return KMX_OK;
+        }
+        // not a batch for the small kernel (too many hits, long candidate lists): the general path below
+    }
     HIP_TRY(r->in_qranks.ensure(std::max<uint64_t>(n_letters, 1) + 16));
     HIP_TRY(r->in_qoff.ensure((nq + 1) * 8));
     if (n_letters) HIP_TRY(hipMemcpyAsync(r->in_qranks.p, qranks + l0, n_letters, hipMemcpyHostToDevice, r->own_stream));
@@ -1432,6 +1473,22 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: result is NULL");
     if (!r->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: the result spans several devices: use kmx_result_part_view_device");
+    if (r->small_valid) {
+        // the last search ran on the latency path and left nothing in HBM: run the same queries (they are still in the
+        // mailbox) through the device form now
+        kmx_result* rr = const_cast<kmx_result*>(r);
+        kmx_index* ix = const_cast<kmx_index*>(rr->index);
+        const unsigned char* mb = rr->mailbox.as<unsigned char>();
+        const uint64_t nq = rr->nq, n_letters = reinterpret_cast<const uint64_t*>(mb)[nq];
+        HIP_TRY(hipSetDevice(rr->device));
+        HIP_TRY(rr->in_qranks.ensure(std::max<uint64_t>(n_letters, 1) + 16));
+        HIP_TRY(rr->in_qoff.ensure((nq + 1) * 8));
+        HIP_TRY(hipMemcpyAsync(rr->in_qoff.p, mb, (nq + 1) * 8, hipMemcpyHostToDevice, rr->own_stream));
+        if (n_letters) HIP_TRY(hipMemcpyAsync(rr->in_qranks.p, mb + (nq + 1) * 8, n_letters, hipMemcpyHostToDevice, rr->own_stream));
+        kmx_result* self = rr;
+        const kmx_status st = kmx_search_batch_device(ix, rr->in_qranks.p, rr->in_qoff.p, nq, rr->flags, rr->own_stream, &self);
+        if (st != KMX_OK) return st;
+    }
     if (r->ctx.pending) { kmx_status fs = search_finish(const_cast<kmx_result*>(r)); if (fs != KMX_OK) return fs; }
     if (d_hit_off) *d_hit_off = r->hit_off.as<uint64_t>();
     if (d_positions) *d_positions = r->out.as<uint32_t>();
@@ -1463,6 +1520,14 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
             kmx_result* p = r->parts[i];
             const uint64_t q0 = r->part_q0[i], nqp = r->part_q0[i + 1] - q0;
             HIP_TRY(hipSetDevice(p->device));
+            if (p->small_valid) {                                   // the part's result already is on the host
+                memcpy(r->v_hit_off + q0 + 1, p->v_hit_off + 1, nqp * 8);
+                memcpy(r->v_status + q0, p->v_status, nqp);
+                memcpy(r->v_kinds + q0, p->v_kinds, nqp);
+                if (have_pos && p->n_hits) memcpy(r->v_positions + h0, p->v_positions, p->n_hits * 4);
+                h0 += p->n_hits;
+                continue;
+            }
             if (nqp) {
                 HIP_TRY(hipMemcpyAsync(r->v_hit_off + q0 + 1, p->hit_off.as<uint64_t>() + 1, nqp * 8, hipMemcpyDeviceToHost, p->stream));
                 HIP_TRY(hipMemcpyAsync(r->v_status + q0, p->status.p, nqp, hipMemcpyDeviceToHost, p->stream));
@@ -1475,7 +1540,7 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
         for (size_t i = 0; i < r->parts.size(); ++i) {
             kmx_result* p = r->parts[i];
             HIP_TRY(hipSetDevice(p->device));
-            HIP_TRY(hipStreamSynchronize(p->stream));
+            if (!p->small_valid && r->part_q0[i + 1] > r->part_q0[i]) HIP_TRY(hipStreamSynchronize(p->stream));
             p->quiesced = true;
             if (h0)
                 for (uint64_t q = r->part_q0[i] + 1; q <= r->part_q0[i + 1]; ++q) r->v_hit_off[q] += h0;
@@ -1576,10 +1641,14 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
         if (r->n_mask_words) HIP_TRY(hipMemcpy(r->h_mask_words.p, r->mask_words.p, r->n_mask_words * 8, hipMemcpyDeviceToHost));
         r->host_masks_valid = true;
     }
-    if (mask_base) *mask_base = r->h_mask_base.as<uint64_t>();
-    if (mask_words) *mask_words = r->h_mask_words.as<uint64_t>();
-    if (cand_count) *cand_count = r->h_cand_count.as<uint32_t>();
-    if (cand_src) *cand_src = r->h_cand_src.as<uint64_t>();
+    if (!r->small_valid) {
+        r->m_base = r->h_mask_base.as<uint64_t>(); r->m_words = r->h_mask_words.as<uint64_t>();
+        r->m_ccnt = r->h_cand_count.as<uint32_t>(); r->m_csrc = r->h_cand_src.as<uint64_t>();
+    }
+    if (mask_base) *mask_base = r->m_base;
+    if (mask_words) *mask_words = r->m_words;
+    if (cand_count) *cand_count = r->m_ccnt;
+    if (cand_src) *cand_src = r->m_csrc;
     return KMX_OK;
 }
 

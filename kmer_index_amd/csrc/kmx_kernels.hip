@@ -206,6 +206,228 @@ __device__ __forceinline__ void bitonic_lds(uint32_t* sbuf, uint32_t n2, uint32_
     }
 }
 
+// The per-query half of kmer_index::search (kmer_index.hpp:505-558 -> :193-346): planner entry, rank-hashes, bucket probes,
+// the sub-k prefix range with its last-kmer fix-up, the parts of a long query.  Shared by k_lookup (every query that is
+// not a plain exact lookup) and k_small (all of them).  elems_s: the element descriptors (LDS copy or ix->elems).
+struct LookupOut {
+    uint64_t src, aux, key, p1;   // as QueryDesc
+    uint32_t cnt, c0;
+    uint8_t kind, status;
+    bool resolved;                // a STITCH query whose few candidates were followed through every part right here
+};
+__device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix, const KmxElemDev* elems_s,
+                                             const uint8_t* __restrict__ qr, uint64_t m, const uint8_t* __restrict__ qend,
+                                             uint32_t flags, LookupOut& o)
+{
+    uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
+    uint64_t src = 0, aux = 0, key = 0;
+    uint64_t p1 = 0;              // STITCH: one further part as (offset in query << 32) | bucket size, bucket in `key`; bit 63: more parts follow
+    uint32_t cnt = 0, c0 = 0;
+    bool resolved = false;
+    const uint32_t sigma = ix->sigma;
+    if (m == 0) {
+        status = KMX_Q_EMPTY_QUERY;                       // assert(query.size() > 0), kmer_index.hpp:195
+    } else if (m >= ix->range) {
+        status = KMX_Q_TOO_LONG;                          // :507-509
+    } else {
+        const KmxPlanEntry pe = load_plan(ix, m);
+        bool ranks_ok = true;
+        // Large k: the buckets hold a handful of positions.  Up to KMX_VRESOLVE start positions of the query are
+        // followed through the parts while those are probed anyway (p + offset_j must be in part j's bucket,
+        // :279-291, :541-551); when the survivors are one run of the first part's bucket the query needs no
+        // validation pass, no mask words and no second read-back: it is filled like an exact lookup.  Not with
+        // KEEP_MASKS (the words are the point there).
+        // Only for elements whose buckets average at most two positions: with longer buckets the extra loads cost more
+        // than the validation they save (BASELINE config 3: +0.16 ms of lookup for -0.05 ms of validation).
+        auto sparse_buckets = [](const KmxElemDev* e) {
+            return e->npos <= 2 * (e->table_kind == KMX_TABLE_DENSE ? e->n_keys : uint64_t(e->n_ukeys));
+        };
+        const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
+        uint32_t cand[KMX_VRESOLVE];
+        uint32_t alive = 0;
+        bool track = false;
+        auto follow = [&](const Run& r, uint32_t delta) {
+            if (r.cnt > KMX_VTINY) { track = false; return; }
+            uint32_t found = 0;
+            for (uint32_t t = 0; t < r.cnt; ++t) {
+                const uint32_t b = ar[r.src + t];
+#pragma unroll
+                for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) found |= uint32_t(cand[i] + delta == b) << i;
+            }
+            alive &= found;
+        };
+        if (pe.scheme == KMX_SCHEME_SINGLE) {
+            const KmxElemDev* el = &elems_s[pe.elem];
+            const uint32_t k = el->k;
+            if (m == k) {                                 // :198-205
+                uint64_t h;
+                ranks_ok = rank_hash(qr, k, sigma, h, qend);
+                if (ranks_ok) {
+                    Run r = probe(el, h);
+                    if (r.cnt) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }
+                }
+            } else if (m < k) {                           // :342-345 -> :115-148
+                const uint64_t R = ix->pw[k - m];         // fast_pow(sigma, k - size)
+                if (R > KMX_SUBK_FANOUT_LIMIT) {
+                    status = KMX_Q_SUBK_FANOUT;           // :119-122
+                } else {
+                    uint64_t hp;
+                    ranks_ok = rank_hash(qr, uint32_t(m), sigma, hp, qend);
+                    if (ranks_ok) {
+                        hp *= R;                          // prefix_hash, :124-129
+                        uint64_t klo, khi;                // key-index range of the prefix
+                        if (el->table_kind == KMX_TABLE_DENSE) {
+                            klo = hp; khi = hp + R;
+                        } else {
+                            const KMX_GLOBAL uint64_t* uk = as_global(el->ukeys);
+                            auto first_key_at_least = [&](uint64_t v) -> uint64_t {
+                                if (!el->dir) return lower_bound_dev<uint64_t>(uk, el->n_ukeys, v);
+                                const uint64_t j = v >> el->dir_shift;              // the directory cell of v
+                                if (j >= el->n_dir) return el->n_ukeys;
+                                const uint32_t c_lo = as_global(el->dir)[j], c_hi = as_global(el->dir)[j + 1];
+                                return c_lo + lower_bound_dev<uint64_t>(uk + c_lo, c_hi - c_lo, v);
+                            };
+                            klo = first_key_at_least(hp);
+                            khi = first_key_at_least(hp + R);
+                        }
+                        const uint32_t lo = as_global(el->offs)[klo], hi = as_global(el->offs)[khi];
+                        // check_last_kmer, :90-112: offsets n-k+i, i in [1, k-m], where no k-mer
+                        // starts but the query still fits.  Bit j of aux <-> position n - j.
+                        const KMX_GLOBAL uint8_t* tail = as_global(ix->tail) + (ix->kmax - k);   // last k letters
+                        uint64_t tmask = 0;
+                        for (uint32_t i = 1; i + m <= k; ++i) {
+                            bool eq = true;
+                            for (uint32_t t = 0; t < m; ++t) eq &= tail[i + t] == qr[t];
+                            if (eq) tmask |= uint64_t(1) << (k - i);
+                        }
+                        const uint32_t len = hi - lo;
+                        cnt = len + uint32_t(__popcll(tmask));
+                        if (cnt) {
+                            kind = KMX_KIND_PREFIX;
+                            src = el->arena_base + lo;
+                            aux = tmask;
+                            key = klo;
+                            c0 = uint32_t(khi - klo);     // number of runs
+                                                    }
+                    }
+                }
+            } else {                                      // m > k, :207-339
+                const uint32_t P = uint32_t(m / k), rest = uint32_t(m % k);
+                bool all = true;
+                Run first{0, 0}, extra{0, 0};
+                uint32_t extra_delta = 0;
+                for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
+                    uint64_t h;
+                    ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h, qend);
+                    if (!ranks_ok) break;
+                    Run r = probe(el, h);
+                    if (j == 0) {
+                        first = r;
+                        track = !(flags & KMX_SEARCH_KEEP_MASKS) && sparse_buckets(el) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
+                        if (track) {
+#pragma unroll
+                            for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) cand[i] = ar[r.src + (i < r.cnt ? i : 0u)];
+                            alive = (1u << r.cnt) - 1u;
+                        }
+                    } else {
+                        extra = r; extra_delta = j * k;
+                        if (track && r.cnt) follow(r, j * k);
+                    }
+                    all = r.cnt != 0;
+                }
+                if (all && ranks_ok) {
+                    if (rest && ix->pw[k - rest] > KMX_SUBK_FANOUT_LIMIT) {
+                        status = KMX_Q_SUBK_FANOUT;       // the rest lookup throws at :119-122 via :234
+                    } else {
+                        if (rest) {
+                            // the rest is verified through the k-mer that ENDS the query
+                            uint64_t h;
+                            ranks_ok = rank_hash(qr + (m - k), k, sigma, h, qend);
+                            if (ranks_ok) { extra = probe(el, h); extra_delta = uint32_t(m - k); }
+                            all = ranks_ok && extra.cnt != 0;
+                            if (all && track) follow(extra, uint32_t(m - k));
+                        }
+                        if (all && ranks_ok) {
+                            kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
+                            key = extra.src;
+                            p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (P - 1 + (rest ? 1 : 0) > 1 ? KMX_P1_MORE : 0);
+                            if (!(flags & KMX_SEARCH_KEEP_MASKS) && first.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
+                            if (track) {
+                                const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
+                                if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
+                                    resolved = true;
+                                    src = first.src + lo;
+                                    cnt = len;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {                                          // multi-k scheme, :515-557
+            // walk _optimal_nk_sum[m] from its last summand to its first
+            uint64_t mm = m;
+            bool all = true;
+            Run r{0, 0}, extra{0, 0};
+            uint32_t extra_delta = 0;
+            const uint32_t nparts = pe.nparts;
+            for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
+                const KmxPlanEntry e = load_plan(ix, mm);
+                const KmxElemDev* el = &elems_s[e.elem];
+                const uint32_t k = el->k;
+                mm -= k;                                  // this summand covers [mm, mm + k)
+                uint64_t h;
+                ranks_ok = rank_hash(qr + mm, k, sigma, h, qend);
+                if (!ranks_ok) break;
+                r = probe(el, h);                         // search_k, :183-190 / :520
+                if (j == 0) {
+                    extra = r; extra_delta = uint32_t(mm);
+                    // the walk meets the LAST summand first: its bucket anchors the start positions p = a - offset
+                    track = !(flags & KMX_SEARCH_KEEP_MASKS) && nparts > 1 && sparse_buckets(el) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
+                    if (track) {
+                        alive = 0;
+#pragma unroll
+                        for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) {
+                            const uint32_t a = ar[r.src + (i < r.cnt ? i : 0u)];
+                            cand[i] = a - uint32_t(mm);
+                            alive |= uint32_t(i < r.cnt && a >= uint32_t(mm)) << i;
+                        }
+                    }
+                } else if (track && r.cnt) {
+                    follow(r, uint32_t(mm));
+                }
+                all = r.cnt != 0;                         // :521-524
+            }
+            if (all && ranks_ok) {
+                if (nparts == 1) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }   // :529-530
+                else {
+                    kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
+                    key = extra.src;
+                    p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (nparts > 2 ? KMX_P1_MORE : 0);
+                    if (!(flags & KMX_SEARCH_KEEP_MASKS) && r.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
+                    if (track) {
+                        // r is the first summand's bucket now (offset 0): which of its entries are surviving starts?
+                        uint32_t fmask = 0;
+                        for (uint32_t t = 0; t < r.cnt; ++t) {
+                            const uint32_t b = ar[r.src + t];
+#pragma unroll
+                            for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) fmask |= uint32_t(((alive >> i) & 1u) && cand[i] == b) << t;
+                        }
+                        const uint32_t lo = fmask ? uint32_t(__ffs(int(fmask))) - 1u : 0u, len = uint32_t(__popc(fmask));
+                        if ((fmask >> lo) == (1u << len) - 1u) {           // one run of the bucket (or nothing)
+                            resolved = true;
+                            src = r.src + lo;
+                            cnt = len;
+                        }
+                    }
+                }
+            }
+        }
+        if (!ranks_ok) { status = KMX_Q_BAD_RANK; kind = KMX_KIND_NONE; cnt = 0; }
+    }
+    o.src = src; o.aux = aux; o.key = key; o.p1 = p1; o.cnt = cnt; o.c0 = c0; o.kind = kind; o.status = status; o.resolved = resolved;
+}
+
 // ---------------------------------------------------------------------------
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
@@ -381,208 +603,10 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         const uint64_t b = qoff[q];
         const uint64_t m = qoff[q + 1] - b;
         const uint8_t* __restrict__ qr = qranks + b;
-        const uint32_t sigma = ix->sigma;
-        if (m == 0) {
-            status = KMX_Q_EMPTY_QUERY;                       // assert(query.size() > 0), kmer_index.hpp:195
-        } else if (m >= ix->range) {
-            status = KMX_Q_TOO_LONG;                          // :507-509
-        } else {
-            const KmxPlanEntry pe = load_plan(ix, m);
-            bool ranks_ok = true;
-            // Large k: the buckets hold a handful of positions.  Up to KMX_VRESOLVE start positions of the query are
-            // followed through the parts while those are probed anyway (p + offset_j must be in part j's bucket,
-            // :279-291, :541-551); when the survivors are one run of the first part's bucket the query needs no
-            // validation pass, no mask words and no second read-back: it is filled like an exact lookup.  Not with
-            // KEEP_MASKS (the words are the point there).
-            // Only for elements whose buckets average at most two positions: with longer buckets the extra loads cost more
-            // than the validation they save (BASELINE config 3: +0.16 ms of lookup for -0.05 ms of validation).
-            auto sparse_buckets = [](const KmxElemDev* e) {
-                return e->npos <= 2 * (e->table_kind == KMX_TABLE_DENSE ? e->n_keys : uint64_t(e->n_ukeys));
-            };
-            const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
-            uint32_t cand[KMX_VRESOLVE];
-            uint32_t alive = 0;
-            bool track = false;
-            auto follow = [&](const Run& r, uint32_t delta) {
-                if (r.cnt > KMX_VTINY) { track = false; return; }
-                uint32_t found = 0;
-                for (uint32_t t = 0; t < r.cnt; ++t) {
-                    const uint32_t b = ar[r.src + t];
-#pragma unroll
-                    for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) found |= uint32_t(cand[i] + delta == b) << i;
-                }
-                alive &= found;
-            };
-            if (pe.scheme == KMX_SCHEME_SINGLE) {
-                const KmxElemDev* el = &elems_s[pe.elem];
-                const uint32_t k = el->k;
-                if (m == k) {                                 // :198-205
-                    uint64_t h;
-                    ranks_ok = rank_hash(qr, k, sigma, h, qend);
-                    if (ranks_ok) {
-                        Run r = probe(el, h);
-                        if (r.cnt) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }
-                    }
-                } else if (m < k) {                           // :342-345 -> :115-148
-                    const uint64_t R = ix->pw[k - m];         // fast_pow(sigma, k - size)
-                    if (R > KMX_SUBK_FANOUT_LIMIT) {
-                        status = KMX_Q_SUBK_FANOUT;           // :119-122
-                    } else {
-                        uint64_t hp;
-                        ranks_ok = rank_hash(qr, uint32_t(m), sigma, hp, qend);
-                        if (ranks_ok) {
-                            hp *= R;                          // prefix_hash, :124-129
-                            uint64_t klo, khi;                // key-index range of the prefix
-                            if (el->table_kind == KMX_TABLE_DENSE) {
-                                klo = hp; khi = hp + R;
-                            } else {
-                                const KMX_GLOBAL uint64_t* uk = as_global(el->ukeys);
-                                auto first_key_at_least = [&](uint64_t v) -> uint64_t {
-                                    if (!el->dir) return lower_bound_dev<uint64_t>(uk, el->n_ukeys, v);
-                                    const uint64_t j = v >> el->dir_shift;              // the directory cell of v
-                                    if (j >= el->n_dir) return el->n_ukeys;
-                                    const uint32_t c_lo = as_global(el->dir)[j], c_hi = as_global(el->dir)[j + 1];
-                                    return c_lo + lower_bound_dev<uint64_t>(uk + c_lo, c_hi - c_lo, v);
-                                };
-                                klo = first_key_at_least(hp);
-                                khi = first_key_at_least(hp + R);
-                            }
-                            const uint32_t lo = as_global(el->offs)[klo], hi = as_global(el->offs)[khi];
-                            // check_last_kmer, :90-112: offsets n-k+i, i in [1, k-m], where no k-mer
-                            // starts but the query still fits.  Bit j of aux <-> position n - j.
-                            const KMX_GLOBAL uint8_t* tail = as_global(ix->tail) + (ix->kmax - k);   // last k letters
-                            uint64_t tmask = 0;
-                            for (uint32_t i = 1; i + m <= k; ++i) {
-                                bool eq = true;
-                                for (uint32_t t = 0; t < m; ++t) eq &= tail[i + t] == qr[t];
-                                if (eq) tmask |= uint64_t(1) << (k - i);
-                            }
-                            const uint32_t len = hi - lo;
-                            cnt = len + uint32_t(__popcll(tmask));
-                            if (cnt) {
-                                kind = KMX_KIND_PREFIX;
-                                src = el->arena_base + lo;
-                                aux = tmask;
-                                key = klo;
-                                c0 = uint32_t(khi - klo);     // number of runs
-                                my_prefix = 1;
-                            }
-                        }
-                    }
-                } else {                                      // m > k, :207-339
-                    const uint32_t P = uint32_t(m / k), rest = uint32_t(m % k);
-                    bool all = true;
-                    Run first{0, 0}, extra{0, 0};
-                    uint32_t extra_delta = 0;
-                    for (uint32_t j = 0; j < P && all && ranks_ok; ++j) {   // :216-227
-                        uint64_t h;
-                        ranks_ok = rank_hash(qr + uint64_t(j) * k, k, sigma, h, qend);
-                        if (!ranks_ok) break;
-                        Run r = probe(el, h);
-                        if (j == 0) {
-                            first = r;
-                            track = !(flags & KMX_SEARCH_KEEP_MASKS) && sparse_buckets(el) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
-                            if (track) {
-#pragma unroll
-                                for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) cand[i] = ar[r.src + (i < r.cnt ? i : 0u)];
-                                alive = (1u << r.cnt) - 1u;
-                            }
-                        } else {
-                            extra = r; extra_delta = j * k;
-                            if (track && r.cnt) follow(r, j * k);
-                        }
-                        all = r.cnt != 0;
-                    }
-                    if (all && ranks_ok) {
-                        if (rest && ix->pw[k - rest] > KMX_SUBK_FANOUT_LIMIT) {
-                            status = KMX_Q_SUBK_FANOUT;       // the rest lookup throws at :119-122 via :234
-                        } else {
-                            if (rest) {
-                                // the rest is verified through the k-mer that ENDS the query
-                                uint64_t h;
-                                ranks_ok = rank_hash(qr + (m - k), k, sigma, h, qend);
-                                if (ranks_ok) { extra = probe(el, h); extra_delta = uint32_t(m - k); }
-                                all = ranks_ok && extra.cnt != 0;
-                                if (all && track) follow(extra, uint32_t(m - k));
-                            }
-                            if (all && ranks_ok) {
-                                kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
-                                key = extra.src;
-                                p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (P - 1 + (rest ? 1 : 0) > 1 ? KMX_P1_MORE : 0);
-                                if (!(flags & KMX_SEARCH_KEEP_MASKS) && first.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
-                                if (track) {
-                                    const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
-                                    if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
-                                        resolved = true;
-                                        src = first.src + lo;
-                                        cnt = len;
-                                    }
-                                }
-                            }
-                        }
-                    }
-                }
-            } else {                                          // multi-k scheme, :515-557
-                // walk _optimal_nk_sum[m] from its last summand to its first
-                uint64_t mm = m;
-                bool all = true;
-                Run r{0, 0}, extra{0, 0};
-                uint32_t extra_delta = 0;
-                const uint32_t nparts = pe.nparts;
-                for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
-                    const KmxPlanEntry e = load_plan(ix, mm);
-                    const KmxElemDev* el = &elems_s[e.elem];
-                    const uint32_t k = el->k;
-                    mm -= k;                                  // this summand covers [mm, mm + k)
-                    uint64_t h;
-                    ranks_ok = rank_hash(qr + mm, k, sigma, h, qend);
-                    if (!ranks_ok) break;
-                    r = probe(el, h);                         // search_k, :183-190 / :520
-                    if (j == 0) {
-                        extra = r; extra_delta = uint32_t(mm);
-                        // the walk meets the LAST summand first: its bucket anchors the start positions p = a - offset
-                        track = !(flags & KMX_SEARCH_KEEP_MASKS) && nparts > 1 && sparse_buckets(el) && r.cnt != 0 && r.cnt <= KMX_VRESOLVE;
-                        if (track) {
-                            alive = 0;
-#pragma unroll
-                            for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) {
-                                const uint32_t a = ar[r.src + (i < r.cnt ? i : 0u)];
-                                cand[i] = a - uint32_t(mm);
-                                alive |= uint32_t(i < r.cnt && a >= uint32_t(mm)) << i;
-                            }
-                        }
-                    } else if (track && r.cnt) {
-                        follow(r, uint32_t(mm));
-                    }
-                    all = r.cnt != 0;                         // :521-524
-                }
-                if (all && ranks_ok) {
-                    if (nparts == 1) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }   // :529-530
-                    else {
-                        kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
-                        key = extra.src;
-                        p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (nparts > 2 ? KMX_P1_MORE : 0);
-                        if (!(flags & KMX_SEARCH_KEEP_MASKS) && r.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
-                        if (track) {
-                            // r is the first summand's bucket now (offset 0): which of its entries are surviving starts?
-                            uint32_t fmask = 0;
-                            for (uint32_t t = 0; t < r.cnt; ++t) {
-                                const uint32_t b = ar[r.src + t];
-#pragma unroll
-                                for (uint32_t i = 0; i < KMX_VRESOLVE; ++i) fmask |= uint32_t(((alive >> i) & 1u) && cand[i] == b) << t;
-                            }
-                            const uint32_t lo = fmask ? uint32_t(__ffs(int(fmask))) - 1u : 0u, len = uint32_t(__popc(fmask));
-                            if ((fmask >> lo) == (1u << len) - 1u) {           // one run of the bucket (or nothing)
-                                resolved = true;
-                                src = r.src + lo;
-                                cnt = len;
-                            }
-                        }
-                    }
-                }
-            }
-            if (!ranks_ok) { status = KMX_Q_BAD_RANK; kind = KMX_KIND_NONE; cnt = 0; my_prefix = 0; }
-        }
+        LookupOut lo;
+        lookup_query(ix, elems_s, qr, m, qend, flags, lo);
+        kind = lo.kind; status = lo.status; src = lo.src; aux = lo.aux; key = lo.key; p1 = lo.p1; cnt = lo.cnt; c0 = lo.c0; resolved = lo.resolved;
+        my_prefix = kind == KMX_KIND_PREFIX;
         if (kind == KMX_KIND_STITCH && !resolved) {
             my_stitch = 1;
             my_words = uint64_t(c0) / 64 + 1;                 // compressed_bitset.hpp:23
@@ -1251,6 +1275,212 @@ __device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t v, uint64_
     __syncthreads();
     if (total_out) *total_out = total;
     return carry + inc - v;
+}
+
+// ---------------------------------------------------------------------------
+// k_small — a handful of queries, start to finish in ONE launch of ONE workgroup.
+//
+// The general pipeline costs a batch of one 80-100 us: two input copies, three to five launches, a counter read-back and
+// four to eight result copies, each a host round trip; the reference answers the same call in about a microsecond
+// (kmer_index.hpp:505-558 on a warm hash map).  Here the queries are read from, and the complete result — hit_off,
+// positions (= to_vector(), kmer_index_result.hpp:244-260), status, kinds, and for cross-referenced queries the candidate
+// run + compressed_bitset words (kmer_index_result.hpp:15-24) — is written to one page-locked host block by the kernel
+// itself: one launch and one stream wait per call.  Thread = query for the lookups (lookup_query, shared with k_lookup),
+// the workgroup together for validation, sort and copy.  Same results as the general path, bit for bit.  A batch this
+// kernel is not made for (too many hits, long candidate lists) sets `fallback` and the host takes the general path.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
+                                                     unsigned char* __restrict__ mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char s_in[KMX_SMALL_IN_BYTES + 16];
+    __shared__ KmxElemDev elems_s[KMX_MAX_KS];
+    __shared__ uint64_t s_src[KMX_SMALL_NQ], s_aux[KMX_SMALL_NQ], s_key[KMX_SMALL_NQ], s_p1[KMX_SMALL_NQ];
+    __shared__ uint32_t s_cnt[KMX_SMALL_NQ], s_c0[KMX_SMALL_NQ], s_off[KMX_SMALL_NQ + 1];
+    __shared__ uint8_t s_kind[KMX_SMALL_NQ], s_status[KMX_SMALL_NQ];
+    __shared__ uint64_t s_words[KMX_SMALL_WORDS];
+    __shared__ uint32_t s_sort[KMX_SMALL_SORT];
+    __shared__ uint32_t s_slow[KMX_SMALL_SLOW], s_wbase[KMX_SMALL_SLOW];
+    __shared__ uint32_t s_n_slow, s_n_words, s_bad, s_valid, s_n_stitch, s_n_prefix, s_n_error, s_n_none;
+    const uint32_t tid = threadIdx.x, lane = lane_id();
+    KmxSmallHeader* __restrict__ hdr = reinterpret_cast<KmxSmallHeader*>(mailbox + KMX_SMALL_OFF_HEADER);
+
+    // 0. the queries out of host memory (one PCIe round trip for the lot), the element descriptors out of HBM
+    {
+        const uint32_t in_bytes = (nq + 1) * 8 + n_letters;
+        const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(mailbox);
+        uint4* dst4 = reinterpret_cast<uint4*>(s_in);
+        for (uint32_t i = tid; i < (in_bytes + 15) / 16; i += KMX_BLOCK) dst4[i] = src4[i];
+        const uint32_t n_words = ix->n_ks * uint32_t(sizeof(KmxElemDev) / 8);
+        const uint64_t* __restrict__ srcw = reinterpret_cast<const uint64_t*>(ix->elems);
+        uint64_t* dstw = reinterpret_cast<uint64_t*>(elems_s);
+        for (uint32_t i = tid; i < n_words; i += KMX_BLOCK) dstw[i] = srcw[i];
+        if (tid == 0) { s_n_slow = s_n_words = s_bad = s_n_stitch = s_n_prefix = s_n_error = s_n_none = 0; }
+    }
+    __syncthreads();
+    const uint64_t* s_qoff = reinterpret_cast<const uint64_t*>(s_in);
+    const uint8_t* s_qr = s_in + (nq + 1) * 8;
+    const uint8_t* s_qend = s_qr + n_letters;
+
+    // 1. thread = query: the descriptor (KEEP_MASKS: every cross-referenced query goes through the validation below)
+    {
+        LookupOut lo;
+        lo.src = lo.aux = lo.key = lo.p1 = 0; lo.cnt = lo.c0 = 0; lo.kind = KMX_KIND_NONE; lo.status = KMX_Q_OK; lo.resolved = false;
+        if (tid < nq) {
+            const uint64_t b = s_qoff[tid], m = s_qoff[tid + 1] - b;
+            lookup_query(ix, elems_s, s_qr + b, m, s_qend, flags | KMX_SEARCH_KEEP_MASKS, lo);
+            bool slow = false;
+            uint32_t words = 0;
+            if (lo.kind == KMX_KIND_STITCH) {
+                slow = true;
+                words = lo.c0 / 64 + 1;                                // compressed_bitset.hpp:23
+                if (lo.c0 > KMX_SMALL_SORT) atomicOr(&s_bad, 1u);
+                atomicAdd(&s_n_stitch, 1u);
+            } else if (lo.kind == KMX_KIND_PREFIX) {
+                const uint32_t len = lo.cnt - uint32_t(__popcll(lo.aux));
+                slow = lo.c0 > 1 && len > 1;                           // several runs: the slice wants sorting (kmer_index_result.hpp:258)
+                if (slow && len > KMX_SMALL_SORT) atomicOr(&s_bad, 1u);
+                atomicAdd(&s_n_prefix, 1u);
+            }
+            if (lo.status != KMX_Q_OK) atomicAdd(&s_n_error, 1u);
+            else if (lo.kind == KMX_KIND_NONE) atomicAdd(&s_n_none, 1u);
+            if (slow) {
+                const uint32_t slot = atomicAdd(&s_n_slow, 1u);
+                if (slot < KMX_SMALL_SLOW) {
+                    s_slow[slot] = tid;
+                    s_wbase[slot] = words ? atomicAdd(&s_n_words, words) : 0u;
+                    if (words) lo.aux = s_wbase[slot];                 // STITCH: index of the first mask word
+                }
+            }
+        }
+        s_src[tid] = lo.src; s_aux[tid] = lo.aux; s_key[tid] = lo.key; s_p1[tid] = lo.p1;
+        s_cnt[tid] = lo.cnt; s_c0[tid] = lo.c0; s_kind[tid] = lo.kind; s_status[tid] = lo.status;
+    }
+    __syncthreads();
+    if (s_bad || s_n_slow > KMX_SMALL_SLOW) {
+        if (tid == 0) hdr->fallback = 1;
+        return;
+    }
+    const uint32_t n_slow = s_n_slow;
+
+    // 2. cross-referenced queries: candidate p of the first part's bucket survives when every further part holds p + its
+    //    offset (kmer_index.hpp:279-291, :541-551); 64 candidates = one wave ballot = one compressed_bitset word
+    for (uint32_t si = 0; si < n_slow; ++si) {
+        const uint32_t q = s_slow[si];
+        if (s_kind[q] != KMX_KIND_STITCH) continue;                    // workgroup-uniform
+        const uint64_t src = s_src[q] & ~SRC_FLAGS;
+        const uint32_t c0 = s_c0[q], wbase = s_wbase[si];
+        if (tid == 0) s_valid = 0;
+        __syncthreads();
+        uint32_t mine = 0;
+        for (uint32_t c = tid; c < ((c0 + 64) & ~63u); c += KMX_BLOCK) {      // (c0 + 64) & ~63: covers word c0 / 64 even when c0 % 64 == 0
+            bool ok = false;
+            if (c < c0) ok = stitch_parts_hold(ix, arena, s_qr, s_qoff, q, arena[src + c], 0u, 1u);
+            const uint64_t bal = __ballot(ok);
+            if (lane == 0) { s_words[wbase + c / 64] = bal; mine += uint32_t(__popcll(bal)); }
+        }
+        if (lane == 0 && mine) atomicAdd(&s_valid, mine);
+        __syncthreads();
+        if (tid == 0) s_cnt[q] = s_valid;
+        __syncthreads();
+    }
+
+    // 3. offsets of the hit lists
+    {
+        uint64_t total = 0;
+        const uint64_t ex = block_exclusive_scan_u64(tid < nq ? s_cnt[tid] : 0u, &total);
+        if (total > KMX_SMALL_POS) {
+            if (tid == 0) hdr->fallback = 1;
+            return;
+        }
+        s_off[tid] = uint32_t(ex);
+        if (tid == 0) s_off[KMX_SMALL_NQ] = uint32_t(total);
+    }
+    __syncthreads();
+    const uint32_t total = s_off[KMX_SMALL_NQ];
+
+    // 4. the per-query arrays and the mask words, straight into the host block
+    {
+        uint64_t* __restrict__ o_off = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_HITOFF);
+        uint64_t* __restrict__ o_csrc = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_CSRC);
+        uint64_t* __restrict__ o_mbase = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_MBASE);
+        uint32_t* __restrict__ o_ccnt = reinterpret_cast<uint32_t*>(mailbox + KMX_SMALL_OFF_CCNT);
+        uint64_t* __restrict__ o_words = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_WORDS);
+        if (tid < nq) {
+            o_off[tid] = s_off[tid];
+            o_csrc[tid] = s_src[tid] & ~SRC_FLAGS;
+            o_mbase[tid] = s_aux[tid];
+            o_ccnt[tid] = s_c0[tid];
+            mailbox[KMX_SMALL_OFF_STATUS + tid] = s_status[tid];
+            mailbox[KMX_SMALL_OFF_KINDS + tid] = s_kind[tid];
+        }
+        if (tid == 0) o_off[nq] = total;
+        for (uint32_t w = tid; w < s_n_words; w += KMX_BLOCK) o_words[w] = s_words[w];
+    }
+    uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(mailbox + KMX_SMALL_OFF_POS);
+
+    // 5a. plain copies, slot-centric: every output slot finds its query (the last one whose offset is <= the slot) and
+    //     copies its element; the slots of slow queries are left to 5b
+    for (uint32_t s = tid; s < total; s += KMX_BLOCK) {
+        uint32_t lo = 0, hi = nq;                                       // last q in [0, nq) with s_off[q] <= s
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= s) lo = mid; else hi = mid; }
+        const uint32_t q = lo, idx = s - s_off[q];
+        const uint8_t kind = s_kind[q];
+        if (kind == KMX_KIND_EXACT) {
+            out[s] = arena[s_src[q] + idx];
+        } else if (kind == KMX_KIND_PREFIX) {
+            // the slice of every k-mer with this prefix, then the last-kmer offsets (kmer_index.hpp:138-146): bit j of aux <-> n - j
+            const uint64_t tmask = s_aux[q];
+            const uint32_t len = s_cnt[q] - uint32_t(__popcll(tmask));
+            if (idx < len) {
+                if (s_c0[q] <= 1 || len <= 1) out[s] = arena[(s_src[q] & ~SRC_FLAGS) + idx];     // one run: already ascending
+            } else {
+                uint32_t t = idx - len;                                 // t-th smallest position = t-th highest bit
+                uint64_t mm = tmask;
+                int bit = 63 - __clzll(mm);
+                while (t--) { mm &= ~(uint64_t(1) << bit); bit = 63 - __clzll(mm); }
+                out[s] = uint32_t(ix->n - uint64_t(bit));
+            }
+        }
+    }
+    // 5b. the slow ones, one at a time
+    for (uint32_t si = 0; si < n_slow; ++si) {
+        const uint32_t q = s_slow[si];
+        const uint64_t src = s_src[q] & ~SRC_FLAGS;
+        if (s_kind[q] == KMX_KIND_STITCH) {
+            // decode the mask words: survivor of candidate c lands at the number of set bits before it (is_valid + push_back,
+            // kmer_index_result.hpp:250-256; the candidates are ascending, so is the list)
+            const uint32_t c0 = s_c0[q], wbase = s_wbase[si];
+            for (uint32_t c = tid; c < c0; c += KMX_BLOCK) {
+                const uint64_t w = s_words[wbase + c / 64];
+                if ((w >> (c & 63)) & 1u) {
+                    uint32_t rank = uint32_t(__popcll(w & ((uint64_t(1) << (c & 63)) - 1)));
+                    for (uint32_t j = 0; j < c / 64; ++j) rank += uint32_t(__popcll(s_words[wbase + j]));
+                    out[s_off[q] + rank] = arena[src + c];
+                }
+            }
+        } else {
+            const uint32_t len = s_cnt[q] - uint32_t(__popcll(s_aux[q]));
+            uint32_t n2 = 2;
+            while (n2 < len) n2 <<= 1;
+            __syncthreads();                                            // s_sort is free again
+            for (uint32_t t = tid; t < n2; t += KMX_BLOCK) s_sort[t] = t < len ? arena[src + t] : 0xFFFFFFFFu;
+            __syncthreads();
+            bitonic_lds(s_sort, n2, tid, uint32_t(KMX_BLOCK), [] { __syncthreads(); });
+            for (uint32_t t = tid; t < len; t += KMX_BLOCK) out[s_off[q] + t] = s_sort[t];
+        }
+    }
+    if (tid == 0) {
+        hdr->nq = nq;
+        hdr->n_hits = total;
+        hdr->n_mask_words = s_n_words;
+        hdr->n_stitch = s_n_stitch; hdr->n_prefix = s_n_prefix; hdr->n_error = s_n_error; hdr->n_none = s_n_none;
+        hdr->fallback = 0;
+    }
+}
+
+void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags)
+{
+    hipLaunchKernelGGL(k_small, dim3(1), dim3(KMX_BLOCK), 0, s, ix, arena, mailbox, nq, n_letters, flags);
 }
 
 __global__ __launch_bounds__(KMX_BLOCK) void k_scan_reduce(const uint32_t* __restrict__ in, uint64_t n,

@@ -98,6 +98,33 @@ struct KmxIndexDev {
 // 128 KB of LDS, k_prefix_sort_block); beyond that the global merge passes.
 #define KMX_PSORT_BLOCK_CAP 32768
 
+// k_small — the latency path of a handful of queries (kmer_index::search(query) is a batch of one): ONE kernel, one
+// workgroup, reads the queries from and writes the complete result to a page-locked host block ("mailbox").
+#define KMX_SMALL_NQ 256          // queries per batch
+#define KMX_SMALL_IN_BYTES 8192   // (nq + 1) offsets + letters, staged in LDS
+#define KMX_SMALL_SORT 4096       // positions of a multi-run PREFIX slice (sorted in LDS) / candidates of a STITCH query
+#define KMX_SMALL_SLOW 8          // STITCH + multi-run PREFIX queries per batch (the workgroup takes them one at a time)
+#define KMX_SMALL_WORDS (KMX_SMALL_SLOW * (KMX_SMALL_SORT / 64 + 1))
+#define KMX_SMALL_POS 49152       // hit positions per batch
+struct KmxSmallHeader {
+    uint32_t fallback;            // 1: the batch is not for this kernel (too many hits / slow queries): nothing else is valid
+    uint32_t nq;
+    uint64_t n_hits, n_mask_words;
+    uint32_t n_stitch, n_prefix, n_error, n_none;
+    uint32_t pad[6];
+};
+// layout of the mailbox: [input: qoff, letters][KmxSmallHeader][the arrays below], offsets in bytes
+#define KMX_SMALL_OFF_HEADER KMX_SMALL_IN_BYTES
+#define KMX_SMALL_OFF_HITOFF (KMX_SMALL_OFF_HEADER + 64)
+#define KMX_SMALL_OFF_CSRC (KMX_SMALL_OFF_HITOFF + (KMX_SMALL_NQ + 1) * 8)
+#define KMX_SMALL_OFF_MBASE (KMX_SMALL_OFF_CSRC + KMX_SMALL_NQ * 8)
+#define KMX_SMALL_OFF_CCNT (KMX_SMALL_OFF_MBASE + KMX_SMALL_NQ * 8)
+#define KMX_SMALL_OFF_STATUS (KMX_SMALL_OFF_CCNT + KMX_SMALL_NQ * 4)
+#define KMX_SMALL_OFF_KINDS (KMX_SMALL_OFF_STATUS + KMX_SMALL_NQ)
+#define KMX_SMALL_OFF_WORDS (KMX_SMALL_OFF_KINDS + KMX_SMALL_NQ)
+#define KMX_SMALL_OFF_POS (KMX_SMALL_OFF_WORDS + KMX_SMALL_WORDS * 8)
+#define KMX_SMALL_BYTES (KMX_SMALL_OFF_POS + KMX_SMALL_POS * 4)
+
 // Counter block written by the lookup kernel and read back once per batch.
 enum {
     KMX_CTR_EXACT = 0,

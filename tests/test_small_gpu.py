@@ -1,0 +1,104 @@
+"""The latency path (k_small): a batch of up to 256 queries through the host-buffer entry point is ONE launch
+that reads the queries from and writes the complete result to a page-locked block.  Its results — hit lists, statuses,
+kinds, candidate runs and compressed_bitset words — must equal the general pipeline's bit for bit; a batch that is not made
+for it falls back to the general pipeline on its own."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from kmer_index_amd import synth
+from tests.helpers import make_queries, pack
+
+pytestmark = pytest.mark.gpu
+
+
+def _lists(off, pos):
+    return [pos[int(off[i]):int(off[i + 1])] for i in range(off.size - 1)]
+
+
+def _words(ptr, n):
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_uint64)), shape=(max(int(n), 1),)).copy()
+
+
+@pytest.mark.parametrize("sigma,ks,table", [(4, [8, 10, 12], "auto"), (4, [6], "open"), (5, [7, 9], "auto"), (20, [3, 4], "open")])
+def test_small_batches_equal_the_general_pipeline(engine, sigma, ks, table):
+    text = synth.ranks(1003 + sigma, 300_000, sigma)
+    kmax = max(ks)
+    lengths = sorted(set([1, 2, max(1, ks[0] - 2), ks[0], ks[0] + 1, kmax, kmax + 3, 2 * ks[0], 2 * kmax, 2 * kmax + 1, 3 * kmax + 2]))
+    qranks, qoff = make_queries(text, sigma, lengths, 60, seed=7)          # random / planted / tail-planted per length
+    nq = qoff.size - 1
+    assert nq > 256
+    idx = engine.Index(text, sigma, ks, table=engine.TABLE_OPEN if table == "open" else engine.TABLE_AUTO, keep_host_arena=True)
+    idx.stats_enable(True)
+    big = idx.search(qranks, qoff, flags=engine.SEARCH_KEEP_MASKS)          # > 256 queries: the general pipeline
+    assert idx.stats()["k_small"]["launches"] == 0
+    g_off, g_pos, g_st, g_kd = big.host()
+    g_base, g_wptr, g_ccnt, g_csrc = big.masks()
+    g_words = _words(g_wptr, int((g_base + g_ccnt // 64 + 1)[g_kd == engine.KIND_STITCH].max()) if (g_kd == engine.KIND_STITCH).any() else 1)
+    want = _lists(g_off, g_pos)
+    assert (g_kd == engine.KIND_STITCH).sum() > 20 and (g_kd == engine.KIND_PREFIX).sum() > 20 and (g_kd == engine.KIND_EXACT).sum() > 20
+    rng = np.random.default_rng(5)
+    order = rng.permutation(nq)
+    res = engine.Result()
+    n_small = 0
+    at = 0
+    for size in [1, 1, 1, 2, 3, 5, 8, 13, 64, 255, 256, 100, 1, 7]:
+        sel = order[at:at + size] if at + size <= nq else order[:size]
+        at += size
+        q, off = pack([qranks[int(qoff[i]):int(qoff[i + 1])] for i in sel])
+        before = idx.stats()["k_small"]["launches"]
+        r = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS, result=res)
+        n_small += idx.stats()["k_small"]["launches"] - before
+        h_off, h_pos, h_st, h_kd = r.host()
+        assert np.array_equal(h_st, g_st[sel]) and np.array_equal(h_kd, g_kd[sel])
+        for j, i in enumerate(sel):
+            assert np.array_equal(h_pos[int(h_off[j]):int(h_off[j + 1])], want[i]), (size, j, i)
+        c = r.counts()
+        assert c["nq"] == size and c["n_hits"] == h_pos.size and c["n_stitch"] == int((h_kd == engine.KIND_STITCH).sum())
+        assert c["n_prefix"] == int((h_kd == engine.KIND_PREFIX).sum()) and c["n_error"] == int((h_st != 0).sum())
+        base, wptr, ccnt, csrc = r.masks()
+        st = np.nonzero(h_kd == engine.KIND_STITCH)[0]
+        if st.size:
+            words = _words(wptr, int((base + ccnt // 64 + 1)[st].max()))
+            for j in st:
+                i = sel[j]
+                nw = int(ccnt[j]) // 64 + 1
+                assert ccnt[j] == g_ccnt[i] and csrc[j] == g_csrc[i]
+                assert np.array_equal(words[int(base[j]):int(base[j]) + nw], g_words[int(g_base[i]):int(g_base[i]) + nw])
+    assert n_small >= 12, "the small batches did not take the latency path"
+    # device views of a result that was produced on the latency path: materialised on demand, same contents
+    import torch
+    q, off = pack([qranks[int(qoff[i]):int(qoff[i + 1])] for i in order[:9]])
+    r = idx.search(q, off, result=res)
+    host = r.host()
+    t_off, t_pos = r.device_tensors(torch.device("cuda", 0))
+    torch.cuda.synchronize()
+    assert np.array_equal(t_off.cpu().numpy().astype(np.uint64), host[0]) and np.array_equal(t_pos.cpu().numpy().view(np.uint32), host[1])
+    res.close()
+    big.close()
+    idx.close()
+
+
+def test_batches_the_small_kernel_declines_fall_back(engine, orc):
+    """More hits than the mailbox holds, long candidate lists, many cross-referenced queries: same answers, general pipeline."""
+    text = synth.ranks(3, 2_000_000, 4)
+    idx = engine.Index(text, 4, [4, 6])
+    idx.stats_enable(True)
+    oidx = orc.Index(text, 4, [4, 6])
+    cases = {
+        "too many hits": pack([text[100:104]] * 30),                                    # 30 x ~7800 hits
+        "long candidate list": pack([text[500:512]]),                                   # 6 + 6: ~490 candidates (fine) ...
+        "huge candidate list": pack([text[500:508]]),                                   # 4 + 4: ~7800 candidates > 4096
+        "many stitch queries": pack([text[s:s + 13] for s in range(1000, 1020)]),       # 20 cross-referenced queries > 8
+        "long prefix slice": pack([text[700:703]]),                                     # m = 3 < 4: 4 runs, ~31000 positions
+    }
+    for name, (q, off) in cases.items():
+        r = idx.search(q, off)
+        o_off, o_pos, o_st, _ = oidx.search_batch(q, off, mode=orc.MODE_INTENDED)
+        h = r.host()
+        assert np.array_equal(h[0], o_off) and np.array_equal(h[1], o_pos) and np.array_equal(h[2], o_st.astype(np.uint8)), name
+        r.close()
+    st = idx.stats()
+    assert st["k_small"]["launches"] == len(cases) and st["k_lookup"]["launches"] >= 4    # tried, declined, served by the general path
+    idx.close()

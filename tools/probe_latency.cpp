@@ -1,0 +1,44 @@
+// Latency of kmer_index::search(query).to_vector() through the C++ host mirror — the reference's call shape
+// (test_main.cpp:41-42): a batch of one.  Build + run: python tools/probe_latency_cpp.py
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <vector>
+
+#include <kmer_index_amd/kmer_index.hpp>
+
+using kmer::alphabet::dna4;
+
+static std::uint64_t mix64(std::uint64_t z)
+{
+    z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 27; z *= 0x94D049BB133111EBull; z ^= z >> 31;
+    return z;
+}
+
+int main()
+{
+    const std::size_t n = 10000000;
+    std::vector<dna4> text(n);
+    for (std::size_t i = 0; i < n; ++i) text[i].assign_rank(std::uint8_t(((mix64(1002 + (i + 1) * 0x9E3779B97F4A7C15ull) >> 32) * 4) >> 32));
+    auto index = kmer::make_kmer_index<8, 10, 12>(text);
+    struct Case { const char* name; std::size_t len; };
+    for (Case c : {Case{"exact  m=10", 10}, Case{"exact  m=12", 12}, Case{"prefix m=9 ", 9}, Case{"stitch m=22", 22}, Case{"stitch m=31", 31}})
+    {
+        std::vector<double> us;
+        std::size_t hits = 0;
+        for (int rep = 0; rep < 300; ++rep)
+        {
+            const std::size_t s = (std::size_t(rep) * 7919 * 131) % (n - c.len);
+            std::vector<dna4> q(text.begin() + s, text.begin() + s + c.len);
+            const auto t0 = std::chrono::steady_clock::now();
+            auto v = index.search(q).to_vector();
+            const auto t1 = std::chrono::steady_clock::now();
+            hits += v.size();
+            if (rep >= 20) us.push_back(std::chrono::duration<double, std::micro>(t1 - t0).count());
+        }
+        std::sort(us.begin(), us.end());
+        std::printf("search(q).to_vector() %s: median %7.1f us  p10 %7.1f  p90 %7.1f  (%.1f hits/query)\n", c.name, us[us.size() / 2],
+                    us[us.size() / 10], us[us.size() * 9 / 10], double(hits) / 300);
+    }
+    return 0;
+}
