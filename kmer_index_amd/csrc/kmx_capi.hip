@@ -1328,8 +1328,18 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
     // A handful of queries (kmer_index::search(query) is a batch of one): one launch that reads the queries from and
     // writes the whole result to a page-locked block — no copies, no counter read-back, one wait.
     static const bool no_small = getenv("KMX_NO_SMALL") != nullptr;
-    if (nq && nq <= KMX_SMALL_NQ && (nq + 1) * 8 + n_letters <= KMX_SMALL_IN_BYTES && !(flags & KMX_SEARCH_COUNT_ONLY) && !no_small &&
-        r->mailbox.ensure_pinned(KMX_SMALL_BYTES)) {
+    bool small = nq && nq <= KMX_SMALL_NQ && (nq + 1) * 8 + n_letters <= KMX_SMALL_IN_BYTES && !(flags & KMX_SEARCH_COUNT_ONLY) && !no_small;
+    if (small && nq > KMX_SMALL_WSLOW) {
+        // queries whose length is none of the index's ks are cross-referenced or sub-k ones: more of them than the kernel
+        // takes would only cost a declined launch
+        uint32_t maybe_slow = 0;
+        for (uint64_t i = 0; i < nq; ++i) {
+            const uint64_t m = qoff[q0 + i + 1] - qoff[q0 + i];
+            maybe_slow += std::find(ix->ks.begin(), ix->ks.end(), uint32_t(m)) == ix->ks.end();
+        }
+        small = maybe_slow <= KMX_SMALL_WSLOW + KMX_SMALL_BSLOW;
+    }
+    if (small && r->mailbox.ensure_pinned(KMX_SMALL_BYTES)) {
         unsigned char* mb = r->mailbox.as<unsigned char>();
         uint64_t* in_off = reinterpret_cast<uint64_t*>(mb);
         for (uint64_t i = 0; i <= nq; ++i) in_off[i] = qoff[q0 + i] - l0;

@@ -1289,20 +1289,36 @@ __device__ __forceinline__ uint64_t block_exclusive_scan_u64(uint64_t v, uint64_
 // the workgroup together for validation, sort and copy.  Same results as the general path, bit for bit.  A batch this
 // kernel is not made for (too many hits, long candidate lists) sets `fallback` and the host takes the general path.
 // ---------------------------------------------------------------------------
+// number of further parts of a cross-referenced query of length m (the parts stitch_parts_hold walks)
+__device__ __forceinline__ uint32_t stitch_n_extra(const KmxIndexDev* __restrict__ ix, uint64_t m)
+{
+    const KmxPlanEntry pe = load_plan(ix, m);
+    if (pe.scheme != KMX_SCHEME_SINGLE) return pe.nparts - 1u;
+    const uint32_t k = ix->elems[pe.elem].k;
+    return uint32_t(m / k) - 1u + ((m % k) ? 1u : 0u);
+}
+
 __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
                                                      unsigned char* __restrict__ mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags)
 {
+    constexpr uint32_t NW = KMX_BLOCK / KMX_WAVE;
+    static_assert(NW * KMX_SMALL_WCAP == KMX_SMALL_SORT, "the waves share the sort buffer of the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char s_in[KMX_SMALL_IN_BYTES + 16];
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];
-    __shared__ uint64_t s_src[KMX_SMALL_NQ], s_aux[KMX_SMALL_NQ], s_key[KMX_SMALL_NQ], s_p1[KMX_SMALL_NQ];
+    __shared__ uint64_t s_src[KMX_SMALL_NQ], s_aux[KMX_SMALL_NQ];
     __shared__ uint32_t s_cnt[KMX_SMALL_NQ], s_c0[KMX_SMALL_NQ], s_off[KMX_SMALL_NQ + 1];
     __shared__ uint8_t s_kind[KMX_SMALL_NQ], s_status[KMX_SMALL_NQ];
     __shared__ uint64_t s_words[KMX_SMALL_WORDS];
-    __shared__ uint32_t s_sort[KMX_SMALL_SORT];
-    __shared__ uint32_t s_slow[KMX_SMALL_SLOW], s_wbase[KMX_SMALL_SLOW];
-    __shared__ uint32_t s_n_slow, s_n_words, s_bad, s_valid, s_n_stitch, s_n_prefix, s_n_error, s_n_none;
-    const uint32_t tid = threadIdx.x, lane = lane_id();
+    __shared__ __attribute__((aligned(16))) uint32_t s_sort[KMX_SMALL_SORT];        // sort buffer; as bytes: the candidates' verdicts
+    __shared__ uint16_t s_wslow[KMX_SMALL_WSLOW], s_bslow[KMX_SMALL_BSLOW];
+    __shared__ uint32_t s_n_wslow, s_n_bslow, s_n_words, s_bad, s_valid, s_n_stitch, s_n_prefix, s_n_error, s_n_none;
+    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
     KmxSmallHeader* __restrict__ hdr = reinterpret_cast<KmxSmallHeader*>(mailbox + KMX_SMALL_OFF_HEADER);
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
 
     // 0. the queries out of host memory (one PCIe round trip for the lot), the element descriptors out of HBM
     {
@@ -1314,7 +1330,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
         const uint64_t* __restrict__ srcw = reinterpret_cast<const uint64_t*>(ix->elems);
         uint64_t* dstw = reinterpret_cast<uint64_t*>(elems_s);
         for (uint32_t i = tid; i < n_words; i += KMX_BLOCK) dstw[i] = srcw[i];
-        if (tid == 0) { s_n_slow = s_n_words = s_bad = s_n_stitch = s_n_prefix = s_n_error = s_n_none = 0; }
+        if (tid == 0) { s_n_wslow = s_n_bslow = s_n_words = s_bad = s_n_stitch = s_n_prefix = s_n_error = s_n_none = 0; }
     }
     __syncthreads();
     const uint64_t* s_qoff = reinterpret_cast<const uint64_t*>(s_in);
@@ -1328,56 +1344,79 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
         if (tid < nq) {
             const uint64_t b = s_qoff[tid], m = s_qoff[tid + 1] - b;
             lookup_query(ix, elems_s, s_qr + b, m, s_qend, flags | KMX_SEARCH_KEEP_MASKS, lo);
-            bool slow = false;
-            uint32_t words = 0;
+            uint32_t size = 0, words = 0;                              // size != 0: a slow query with that many candidates / positions
             if (lo.kind == KMX_KIND_STITCH) {
-                slow = true;
+                size = max(lo.c0, 1u);
                 words = lo.c0 / 64 + 1;                                // compressed_bitset.hpp:23
-                if (lo.c0 > KMX_SMALL_SORT) atomicOr(&s_bad, 1u);
                 atomicAdd(&s_n_stitch, 1u);
             } else if (lo.kind == KMX_KIND_PREFIX) {
                 const uint32_t len = lo.cnt - uint32_t(__popcll(lo.aux));
-                slow = lo.c0 > 1 && len > 1;                           // several runs: the slice wants sorting (kmer_index_result.hpp:258)
-                if (slow && len > KMX_SMALL_SORT) atomicOr(&s_bad, 1u);
+                if (lo.c0 > 1 && len > 1) size = len;                  // several runs: the slice wants sorting (kmer_index_result.hpp:258)
                 atomicAdd(&s_n_prefix, 1u);
             }
             if (lo.status != KMX_Q_OK) atomicAdd(&s_n_error, 1u);
             else if (lo.kind == KMX_KIND_NONE) atomicAdd(&s_n_none, 1u);
-            if (slow) {
-                const uint32_t slot = atomicAdd(&s_n_slow, 1u);
-                if (slot < KMX_SMALL_SLOW) {
-                    s_slow[slot] = tid;
-                    s_wbase[slot] = words ? atomicAdd(&s_n_words, words) : 0u;
-                    if (words) lo.aux = s_wbase[slot];                 // STITCH: index of the first mask word
+            if (size > KMX_SMALL_SORT) atomicOr(&s_bad, 1u);
+            else if (size) {
+                if (size <= KMX_SMALL_WCAP) {
+                    const uint32_t slot = atomicAdd(&s_n_wslow, 1u);
+                    if (slot < KMX_SMALL_WSLOW) s_wslow[slot] = uint16_t(tid);
+                } else {
+                    const uint32_t slot = atomicAdd(&s_n_bslow, 1u);
+                    if (slot < KMX_SMALL_BSLOW) s_bslow[slot] = uint16_t(tid);
                 }
+                if (words) lo.aux = atomicAdd(&s_n_words, words);      // STITCH: index of the first mask word
             }
         }
-        s_src[tid] = lo.src; s_aux[tid] = lo.aux; s_key[tid] = lo.key; s_p1[tid] = lo.p1;
-        s_cnt[tid] = lo.cnt; s_c0[tid] = lo.c0; s_kind[tid] = lo.kind; s_status[tid] = lo.status;
+        s_src[tid] = lo.src; s_aux[tid] = lo.aux; s_cnt[tid] = lo.cnt; s_c0[tid] = lo.c0; s_kind[tid] = lo.kind; s_status[tid] = lo.status;
     }
     __syncthreads();
-    if (s_bad || s_n_slow > KMX_SMALL_SLOW) {
+    if (s_bad || s_n_wslow > KMX_SMALL_WSLOW || s_n_bslow > KMX_SMALL_BSLOW) {
         if (tid == 0) hdr->fallback = 1;
         return;
     }
-    const uint32_t n_slow = s_n_slow;
+    // fewer small slow queries than waves: the whole workgroup takes them too, one after the other (a wave per query would
+    // leave the other waves idle)
+    const bool merge = s_n_wslow < NW;
+    const uint32_t n_wslow = merge ? 0u : s_n_wslow, n_bslow = s_n_bslow + (merge ? s_n_wslow : 0u);
+    auto bslow_at = [&](uint32_t si) -> uint32_t { return si < s_n_bslow ? s_bslow[si] : s_wslow[si - s_n_bslow]; };
 
     // 2. cross-referenced queries: candidate p of the first part's bucket survives when every further part holds p + its
-    //    offset (kmer_index.hpp:279-291, :541-551); 64 candidates = one wave ballot = one compressed_bitset word
-    for (uint32_t si = 0; si < n_slow; ++si) {
-        const uint32_t q = s_slow[si];
-        if (s_kind[q] != KMX_KIND_STITCH) continue;                    // workgroup-uniform
+    //    offset (kmer_index.hpp:279-291, :541-551).  One (candidate, part) pair per thread — a query of a few candidates and
+    //    a few parts is checked in one round trip through the parts' buckets; the verdicts meet in a byte per candidate;
+    //    64 candidates = one ballot = one compressed_bitset word.  `T` threads (a wave or the workgroup) per query.
+    auto validate = [&](uint32_t q, uint32_t t, uint32_t T, uint8_t* ok8, auto sync) -> uint32_t {
         const uint64_t src = s_src[q] & ~SRC_FLAGS;
-        const uint32_t c0 = s_c0[q], wbase = s_wbase[si];
-        if (tid == 0) s_valid = 0;
-        __syncthreads();
+        const uint32_t c0 = s_c0[q], wbase = uint32_t(s_aux[q]);
+        const uint32_t n_extra = stitch_n_extra(ix, s_qoff[q + 1] - s_qoff[q]);
+        for (uint32_t c = t; c < c0; c += T) ok8[c] = 1;
+        sync();
+        for (uint32_t item = t; item < c0 * n_extra; item += T) {
+            const uint32_t c = item / n_extra, e = item - c * n_extra;
+            if (!stitch_parts_hold(ix, arena, s_qr, s_qoff, q, arena[src + c], e, n_extra)) ok8[c] = 0;
+        }
+        sync();
         uint32_t mine = 0;
-        for (uint32_t c = tid; c < ((c0 + 64) & ~63u); c += KMX_BLOCK) {      // (c0 + 64) & ~63: covers word c0 / 64 even when c0 % 64 == 0
-            bool ok = false;
-            if (c < c0) ok = stitch_parts_hold(ix, arena, s_qr, s_qoff, q, arena[src + c], 0u, 1u);
-            const uint64_t bal = __ballot(ok);
+        for (uint32_t c = t; c < ((c0 + 64) & ~63u); c += T) {          // (c0 + 64) & ~63: covers word c0 / 64 even when c0 % 64 == 0
+            const uint64_t bal = __ballot(c < c0 && ok8[c]);
             if (lane == 0) { s_words[wbase + c / 64] = bal; mine += uint32_t(__popcll(bal)); }
         }
+        return mine;                                                    // (lane 0 of every wave: its share of the survivors)
+    };
+    for (uint32_t si = wv; si < n_wslow; si += NW) {                    // a wave per query
+        const uint32_t q = s_wslow[si];
+        if (s_kind[q] != KMX_KIND_STITCH) continue;
+        const uint32_t mine = validate(q, lane, KMX_WAVE, reinterpret_cast<uint8_t*>(s_sort + wv * KMX_SMALL_WCAP), wsync);
+        if (lane == 0) s_cnt[q] = mine;
+        wsync();
+    }
+    __syncthreads();
+    for (uint32_t si = 0; si < n_bslow; ++si) {                         // the workgroup per query
+        const uint32_t q = bslow_at(si);
+        if (s_kind[q] != KMX_KIND_STITCH) continue;                     // workgroup-uniform
+        if (tid == 0) s_valid = 0;
+        __syncthreads();
+        const uint32_t mine = validate(q, tid, KMX_BLOCK, reinterpret_cast<uint8_t*>(s_sort), [] { __syncthreads(); });
         if (lane == 0 && mine) atomicAdd(&s_valid, mine);
         __syncthreads();
         if (tid == 0) s_cnt[q] = s_valid;
@@ -1442,15 +1481,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
             }
         }
     }
-    // 5b. the slow ones, one at a time
-    for (uint32_t si = 0; si < n_slow; ++si) {
-        const uint32_t q = s_slow[si];
+    // 5b. the slow ones.  STITCH: decode the mask words — the survivor of candidate c lands at the number of set bits before
+    //     it (is_valid + push_back, kmer_index_result.hpp:250-256; the candidates are ascending, so is the list).
+    //     PREFIX: the slice sorted in LDS (the std::sort of kmer_index_result.hpp:258).
+    auto emit = [&](uint32_t q, uint32_t t, uint32_t T, uint32_t* sbuf, auto sync) {
         const uint64_t src = s_src[q] & ~SRC_FLAGS;
         if (s_kind[q] == KMX_KIND_STITCH) {
-            // decode the mask words: survivor of candidate c lands at the number of set bits before it (is_valid + push_back,
-            // kmer_index_result.hpp:250-256; the candidates are ascending, so is the list)
-            const uint32_t c0 = s_c0[q], wbase = s_wbase[si];
-            for (uint32_t c = tid; c < c0; c += KMX_BLOCK) {
+            const uint32_t c0 = s_c0[q], wbase = uint32_t(s_aux[q]);
+            for (uint32_t c = t; c < c0; c += T) {
                 const uint64_t w = s_words[wbase + c / 64];
                 if ((w >> (c & 63)) & 1u) {
                     uint32_t rank = uint32_t(__popcll(w & ((uint64_t(1) << (c & 63)) - 1)));
@@ -1462,13 +1500,17 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
             const uint32_t len = s_cnt[q] - uint32_t(__popcll(s_aux[q]));
             uint32_t n2 = 2;
             while (n2 < len) n2 <<= 1;
-            __syncthreads();                                            // s_sort is free again
-            for (uint32_t t = tid; t < n2; t += KMX_BLOCK) s_sort[t] = t < len ? arena[src + t] : 0xFFFFFFFFu;
-            __syncthreads();
-            bitonic_lds(s_sort, n2, tid, uint32_t(KMX_BLOCK), [] { __syncthreads(); });
-            for (uint32_t t = tid; t < len; t += KMX_BLOCK) out[s_off[q] + t] = s_sort[t];
+            sync();                                                     // sbuf is free again
+            for (uint32_t i = t; i < n2; i += T) sbuf[i] = i < len ? arena[src + i] : 0xFFFFFFFFu;
+            sync();
+            bitonic_lds(sbuf, n2, t, T, sync);
+            for (uint32_t i = t; i < len; i += T) out[s_off[q] + i] = sbuf[i];
         }
-    }
+    };
+    __syncthreads();                                                    // (the verdict bytes of step 2 lived in s_sort)
+    for (uint32_t si = wv; si < n_wslow; si += NW) emit(s_wslow[si], lane, KMX_WAVE, s_sort + wv * KMX_SMALL_WCAP, wsync);
+    __syncthreads();
+    for (uint32_t si = 0; si < n_bslow; ++si) emit(bslow_at(si), tid, KMX_BLOCK, s_sort, [] { __syncthreads(); });
     if (tid == 0) {
         hdr->nq = nq;
         hdr->n_hits = total;

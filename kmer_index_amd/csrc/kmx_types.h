@@ -102,9 +102,14 @@ struct KmxIndexDev {
 // workgroup, reads the queries from and writes the complete result to a page-locked host block ("mailbox").
 #define KMX_SMALL_NQ 256          // queries per batch
 #define KMX_SMALL_IN_BYTES 8192   // (nq + 1) offsets + letters, staged in LDS
-#define KMX_SMALL_SORT 4096       // positions of a multi-run PREFIX slice (sorted in LDS) / candidates of a STITCH query
-#define KMX_SMALL_SLOW 8          // STITCH + multi-run PREFIX queries per batch (the workgroup takes them one at a time)
-#define KMX_SMALL_WORDS (KMX_SMALL_SLOW * (KMX_SMALL_SORT / 64 + 1))
+// "slow" queries — cross-referenced ones (STITCH) and sub-k ones whose slice has several runs (PREFIX, wants sorting):
+// up to KMX_SMALL_WSLOW of them with at most KMX_SMALL_WCAP candidates / positions are taken by the workgroup's four waves in
+// parallel, up to KMX_SMALL_BSLOW bigger ones (at most KMX_SMALL_SORT) by the whole workgroup one after the other
+#define KMX_SMALL_WCAP 1024
+#define KMX_SMALL_WSLOW 32
+#define KMX_SMALL_SORT 4096
+#define KMX_SMALL_BSLOW 8
+#define KMX_SMALL_WORDS (KMX_SMALL_WSLOW * (KMX_SMALL_WCAP / 64 + 1) + KMX_SMALL_BSLOW * (KMX_SMALL_SORT / 64 + 1))
 #define KMX_SMALL_POS 49152       // hit positions per batch
 struct KmxSmallHeader {
     uint32_t fallback;            // 1: the batch is not for this kernel (too many hits / slow queries): nothing else is valid
