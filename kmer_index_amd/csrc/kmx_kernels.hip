@@ -1068,9 +1068,11 @@ __device__ void validate_more_wave(const KmxIndexDev* __restrict__ ix, const uin
 // are checked against all other parts, lane = candidate, two per lane, in lockstep.  The survivors go to stitch_hits
 // (ascending, as the anchor's bucket is) and the count to cnt; the mask words of such a query are not produced (nobody
 // reads them without KEEP_MASKS, and with it the query is not flagged).
+#define KMX_BIG_TILE 192       // anchor entries per tile (three per lane): a part as dense as the anchor then needs a window of 256
+#define KMX_BIG_STAGE 2048     // entries of a part's slice staged in LDS per wave
 __device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
                                   const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff, const QueryDesc& d,
-                                  uint32_t q)
+                                  uint32_t q, uint32_t* __restrict__ wstage)
 {
     const uint32_t lane = lane_id();
     const uint64_t qb = qoff[q];
@@ -1123,44 +1125,115 @@ __device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint
             a_src = __shfl(rsrc, owner); a_dl = uint32_t(__shfl(int(rdl), owner));
         }
     }
-    // 2. its entries against every other part
+    // 2. its entries against every other part, a tile of KMX_BIG_TILE entries at a time — a merge of sorted lists in tiles.
+    //    Anchor and parts are ascending, so the start positions [p_lo, p_hi] of a tile can only be met by the entries of a part's
+    //    bucket that lie in [p_lo + offset, p_hi + offset], and those follow the entries the previous tile looked at: every
+    //    part keeps a cursor into its bucket (lane = part), the wave stages a window of the bucket from the cursor on in LDS
+    //    with one coalesced load, searches the tile's candidates there (lockstep halving at LDS latency) and moves the
+    //    cursor past the tile's range.  Linear in the lengths of the lists, one HBM round trip per tile and part, where a
+    //    binary search per candidate and part over whole buckets (kmer_index.hpp:279-291) pays log2(bucket) dependent
+    //    round trips each.  Queries with more than 64 parts keep no cursors: the range of a part is found by two binary
+    //    searches per tile instead.
     uint32_t* __restrict__ hits = d.stitch_hits + d.aux[q] * 64;
     const uint64_t below = (uint64_t(1) << lane) - 1;
+    constexpr int R = KMX_BIG_TILE / KMX_WAVE;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const bool cursors = n_all <= KMX_WAVE;
+    uint64_t c_src = 0;                                                   // this lane's part (cursor mode): bucket, size, offset, cursor
+    uint32_t c_cnt = 0, c_dl = 0, c_cur = 0;
+    uint32_t c_win = KMX_BIG_STAGE;                                       // window: what a tile is expected to need of this bucket (x 1.25), a power of two
+    if (cursors) {
+        part_of(lane, c_src, c_cnt, c_dl);
+        const uint64_t want = (uint64_t(KMX_BIG_TILE) * c_cnt * 5) / (uint64_t(max(a_cnt, 1u)) * 4) + 8;
+        c_win = 64;
+        while (c_win < want && c_win < KMX_BIG_STAGE) c_win <<= 1;
+        const uint32_t e_first = a_cnt ? arena[a_src] : 0u;
+        c_cur = uint32_t(lower_bound_dev<uint32_t>(arena + c_src, c_cnt, (e_first >= a_dl ? e_first - a_dl : 0u) + c_dl));
+    }
     uint32_t kept = 0;
-    for (uint32_t base = 0; base < a_cnt; base += 2 * KMX_WAVE) {
-        const bool v0 = base + lane < a_cnt, v1 = base + KMX_WAVE + lane < a_cnt;
-        const uint32_t e0 = v0 ? arena[a_src + base + lane] : 0u, e1 = v1 ? arena[a_src + base + KMX_WAVE + lane] : 0u;
-        bool a0 = v0 && e0 >= a_dl, a1 = v1 && e1 >= a_dl;            // a start before the text is none
-        const uint32_t p0 = e0 - a_dl, p1 = e1 - a_dl;
-        for (uint32_t pb = 0; pb < n_all && __any(a0 || a1); pb += KMX_WAVE) {
-            uint64_t rsrc; uint32_t rcnt, rdl;
-            part_of(pb + lane, rsrc, rcnt, rdl);
+    for (uint32_t base = 0; base < a_cnt; base += KMX_BIG_TILE) {
+        uint32_t p[R];
+        bool alive[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t i = base + uint32_t(r) * KMX_WAVE + lane;
+            const uint32_t e = i < a_cnt ? arena[a_src + i] : 0u;
+            alive[r] = i < a_cnt && e >= a_dl;                          // a start before the text is none
+            p[r] = e - a_dl;
+        }
+        const uint32_t e_lo = arena[a_src + base], e_hi = arena[a_src + min(base + uint32_t(KMX_BIG_TILE), a_cnt) - 1];
+        const uint32_t p_lo = e_lo >= a_dl ? e_lo - a_dl : 0u, p_hi = e_hi >= a_dl ? e_hi - a_dl : 0u;
+        bool any = false;
+#pragma unroll
+        for (int r = 0; r < R; ++r) any |= alive[r];
+        for (uint32_t pb = 0; pb < n_all && __any(any); pb += KMX_WAVE) {
+            uint64_t rsrc = c_src; uint32_t rcnt = c_cnt, rdl = c_dl, r0 = c_cur, r1 = c_cnt;
+            if (!cursors) {
+                part_of(pb + lane, rsrc, rcnt, rdl);
+                r0 = uint32_t(lower_bound_dev<uint32_t>(arena + rsrc, rcnt, p_lo + rdl));
+                r1 = uint32_t(upper_bound_dev<uint32_t>(arena + rsrc, rcnt, p_hi + rdl));
+            }
             const uint32_t nb = min(uint32_t(KMX_WAVE), n_all - pb);
-            for (uint32_t j = 0; j < nb && __any(a0 || a1); ++j) {
+            for (uint32_t j = 0; j < nb && __any(any); ++j) {
                 if (pb + j == a_e) continue;                            // the anchor itself
-                const uint64_t bs = __shfl(rsrc, int(j));
-                const uint32_t bn = uint32_t(__shfl(int(rcnt), int(j)));
+                const uint32_t s1 = uint32_t(__shfl(int(r1), int(j)));
                 const uint32_t dl = uint32_t(__shfl(int(rdl), int(j)));
-                const uint32_t* __restrict__ bk = arena + bs;
-                const uint32_t last = bn ? bn - 1 : 0u;
-                const uint32_t x0 = p0 + dl, x1 = p1 + dl;
-                uint32_t c0s = 0, c1s = 0;                              // branch-free halving, both searches in lockstep
-                uint64_t P2 = 1;
-                while (P2 <= bn) P2 <<= 1;
-                for (uint32_t st = uint32_t(P2 >> 1); st; st >>= 1) {
-                    const uint32_t t0 = bk[min(c0s + st - 1, last)], t1 = bk[min(c1s + st - 1, last)];
-                    c0s += (c0s + st - 1 < bn && t0 < x0) ? st : 0u;
-                    c1s += (c1s + st - 1 < bn && t1 < x1) ? st : 0u;
+                const uint32_t* __restrict__ bk = arena + __shfl(rsrc, int(j));
+                const uint32_t x_hi = p_hi + dl;
+                uint32_t cur = uint32_t(__shfl(int(r0), int(j)));
+                const uint32_t win = uint32_t(__shfl(int(c_win), int(j)));
+                uint32_t und = 0;                                       // bit r: candidate r is alive and not yet decided for this part
+                uint32_t x[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) { x[r] = p[r] + dl; und |= uint32_t(alive[r]) << r; }
+                for (;;) {                                              // windows of the bucket (wave-uniform control)
+                    const uint32_t W = min(win, s1 > cur ? s1 - cur : 0u);
+                    if (W == 0) break;
+                    uint32_t P2 = 1;
+                    while (P2 < W) P2 <<= 1;
+                    wsync();                                            // the previous window has been searched
+                    for (uint32_t t = lane; t < P2; t += KMX_WAVE) wstage[t] = t < W ? bk[cur + t] : 0xFFFFFFFFu;
+                    wsync();
+                    const uint32_t last_val = wstage[W - 1];
+                    uint32_t pos[R + 1];
+#pragma unroll
+                    for (int r = 0; r <= R; ++r) pos[r] = 0;
+                    for (uint32_t st = P2 >> 1; st; st >>= 1) {         // branch-free halving: the lane's candidates and the tile's end in lockstep
+#pragma unroll
+                        for (int r = 0; r < R; ++r) pos[r] += wstage[pos[r] + st - 1] < x[r] ? st : 0u;
+                        pos[R] += wstage[pos[R] + st - 1] <= x_hi ? st : 0u;
+                    }
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const bool found = wstage[pos[r]] == x[r];      // binary_search :283, lower_bound :544-546
+                        const bool inside = x[r] <= last_val;           // the window covers x: its verdict is final
+                        if (((und >> r) & 1u) && (found || inside)) { und &= ~(1u << r); alive[r] = found; }
+                    }
+                    if (last_val >= x_hi || cur + W >= s1) {
+                        cur += pos[R] + (wstage[pos[R]] <= x_hi ? 1u : 0u);   // entries <= the tile's last value: behind the cursor from now on
+                        break;
+                    }
+                    cur += W;
                 }
-                a0 = a0 && c0s < bn && bk[min(c0s, last)] == x0;       // binary_search :283, lower_bound :544-546
-                a1 = a1 && c1s < bn && bk[min(c1s, last)] == x1;
+#pragma unroll
+                for (int r = 0; r < R; ++r)
+                    if ((und >> r) & 1u) alive[r] = false;              // the bucket ended before reaching p + offset
+                if (cursors && lane == j) c_cur = cur;
+                any = false;
+#pragma unroll
+                for (int r = 0; r < R; ++r) any |= alive[r];
             }
         }
-        const uint64_t b0 = __ballot(a0), b1 = __ballot(a1);
-        if (a0) hits[kept + uint32_t(__popcll(b0 & below))] = p0;
-        kept += uint32_t(__popcll(b0));
-        if (a1) hits[kept + uint32_t(__popcll(b1 & below))] = p1;
-        kept += uint32_t(__popcll(b1));
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint64_t bal = __ballot(alive[r]);
+            if (alive[r]) hits[kept + uint32_t(__popcll(bal & below))] = p[r];
+            kept += uint32_t(__popcll(bal));
+        }
     }
     if (lane == 0) d.cnt[q] = kept;
 }
@@ -1226,6 +1299,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_wave(const KmxIndexDev* 
                                                              const uint64_t* __restrict__ qoff, QueryDesc d,
                                                              uint64_t n_stitch, uint64_t* __restrict__ mask_words)
 {
+    __shared__ uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_BIG_STAGE];
     const uint32_t lane = lane_id();
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
@@ -1243,7 +1317,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_wave(const KmxIndexDev* 
             const int l = __ffsll((unsigned long long)todo) - 1;
             todo &= todo - 1;
             const uint32_t ql = uint32_t(__shfl(int(q), l));
-            if (__shfl(int(whole), l)) validate_big_wave(ix, arena, qranks, qoff, d, ql);
+            if (__shfl(int(whole), l)) validate_big_wave(ix, arena, qranks, qoff, d, ql, stage[threadIdx.x / KMX_WAVE]);
             else validate_more_wave(ix, arena, qranks, qoff, d, ql, uint32_t(__shfl(int(tentative), l)), mask_words);
         }
     }

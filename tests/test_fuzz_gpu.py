@@ -104,6 +104,14 @@ def test_random_index_and_queries(engine, orc, seed):
     res2 = idx.search(qranks, qoff, result=res)
     ho2, pos2, st2, kd2 = res2.host()
     assert np.array_equal(ho2, ho) and np.array_equal(pos2, pos) and np.array_equal(kd2, kd), case
+    # small slices of the same queries: the latency path (k_small) where the batch suits it, same answers either way
+    for size in (1, int(rng.integers(2, 40))):
+        b = int(rng.integers(0, len(qs) - size + 1))
+        sq, so = pack(qs[b:b + size])
+        rs = idx.search(sq, so, flags=flags, result=res)
+        h3, p3, s3, k3 = rs.host()
+        assert np.array_equal(s3, st[b:b + size]) and np.array_equal(k3, kd[b:b + size]), case + f" slice {b}+{size}"
+        assert np.array_equal(h3, ho[b:b + size + 1] - ho[b]) and np.array_equal(p3, pos[int(ho[b]):int(ho[b + size])]), case + f" slice {b}+{size}"
     idx.close()
 
 
