@@ -1069,7 +1069,7 @@ __device__ void validate_more_wave(const KmxIndexDev* __restrict__ ix, const uin
 // (ascending, as the anchor's bucket is) and the count to cnt; the mask words of such a query are not produced (nobody
 // reads them without KEEP_MASKS, and with it the query is not flagged).
 #define KMX_BIG_TILE 192       // anchor entries per tile (three per lane): a part as dense as the anchor then needs a window of 256
-#define KMX_BIG_STAGE 2048     // entries of a part's slice staged in LDS per wave
+#define KMX_BIG_STAGE 1024     // entries of a part's slice staged in LDS per wave
 __device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
                                   const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff, const QueryDesc& d,
                                   uint32_t q, uint32_t* __restrict__ wstage)
