@@ -336,10 +336,7 @@ def worker(args):
 
     t_el = torch.tensor([elapsed, gather_leg["elapsed"] if gather_leg else 0.0], dtype=torch.float64, device=comm_dev)
     total_hits = counts["n_hits"]
-    # the dominant kernel: the single-pass exact search (k_fused) when the steady state took it, else k_fill
-    fused = stats.get("k_fused", {"launches": 0, "total_ms": 0.0})
-    dom_name = "k_fused" if fused["launches"] >= max(1, args.steps // 2) else "k_fill"
-    fill = stats.get(dom_name, {"launches": 0, "total_ms": 0.0})
+    fill = stats.get("k_fill", {"launches": 0, "total_ms": 0.0})
     fill_ms = fill["total_ms"] / max(fill["launches"], 1)
     per_rank = None
     rccl = None
@@ -347,9 +344,7 @@ def worker(args):
         dist.all_reduce(t_el, op=dist.ReduceOp.MAX)                    # max over ranks (the contract's clock)
         totals = kdist.all_gather_totals(nq, counts["n_hits"], device=comm_dev)    # the one exchange: per-shard totals
         total_hits = int(totals[:, 1].sum())
-        # (per-rank algorithmic bytes of the dominant kernel: k_fill moves the lists, k_fused the whole job)
-        my_bytes = 8.0 * counts["n_hits"] + (float(n_letters) + 24.0 * nq if dom_name == "k_fused" else 0.0)
-        mine = torch.tensor([fill_ms, my_bytes, float(elapsed)], dtype=torch.float64, device=comm_dev)
+        mine = torch.tensor([fill_ms, float(counts["n_hits"]), float(elapsed)], dtype=torch.float64, device=comm_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
         per_rank = torch.stack(allr).cpu().numpy()
@@ -431,10 +426,10 @@ def worker(args):
         ms_per_step = elapsed / args.steps * 1e3
         value = n_total_q * args.steps / elapsed / 1e6
         n_hits_rank = counts["n_hits"]
-        # algorithmic bytes: per query R = m + 16 + 4c, W = 8 + 4c.  k_fill moves the 4c + 4c part, k_fused all of it.
+        # algorithmic bytes: per query R = m + 16 + 4c, W = 8 + 4c.  k_fill moves the 4c + 4c part.
+        fill_bytes = 8.0 * n_hits_rank
         read_bytes = float(n_letters) + 16.0 * nq + 4.0 * n_hits_rank
         job_bytes = read_bytes + 8.0 * nq + 4.0 * n_hits_rank
-        fill_bytes = job_bytes if dom_name == "k_fused" else 8.0 * n_hits_rank
         achieved = fill_bytes / (fill_ms * 1e-3) / 1e9 if fill_ms > 0 else 0.0
         kernels_ms = {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in stats.items() if v["launches"]}
         # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 --pmc
@@ -443,13 +438,12 @@ def worker(args):
         for name in ("pmc_summary_current.json", f"pmc_summary_current_cfg{args.config}.json"):
             try:
                 prof = json.load(open(os.path.join(ROOT, "profiles", name)))
-                dom = prof.get("dominant", prof.get("k_fill"))
-                if dom["algorithmic_bytes_per_launch"] == int(fill_bytes) and dom_name in dom["kernel"]:
-                    traffic, traffic_src = dom["hbm_bytes_per_launch"], "profiles/" + name
+                if prof["k_fill"]["algorithmic_bytes_per_launch"] == int(fill_bytes):
+                    traffic, traffic_src = prof["k_fill"]["hbm_bytes_per_launch"], "profiles/" + name
                     break
             except Exception:
                 pass
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+        roofline = {"bound": "hbm", "kernel": "k_fill", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": fill_bytes, "avg_launch_ms": round(fill_ms, 4),
                     "job_algorithmic_GBps": round(job_bytes / (ms_per_step * 1e-3) / 1e9, 1),
@@ -458,7 +452,7 @@ def worker(args):
                     "read_only_GBps": round(read_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                     "read_only_frac": round(read_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)}
         if per_rank is not None:
-            roofline["per_rank_frac"] = [round(b / (f * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if f > 0 else 0.0 for f, b, _ in per_rank]
+            roofline["per_rank_frac"] = [round(8.0 * h / (f * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if f > 0 else 0.0 for f, h, _ in per_rank]
             roofline["per_rank_step_ms"] = [round(e / args.steps * 1e3, 4) for _, _, e in per_rank]
         gather_out = None
         if gather_leg:

@@ -102,11 +102,11 @@ struct HostBuf {
 
 enum KernelId {
     K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK,
-    K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_FUSED, K_COUNT
+    K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_lookup", "k_scan", "k_partition", "k_fill", "k_validate", "k_compact",
-    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block", "k_small", "k_fused"};
+    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block", "k_small"};
 
 struct Stats {
     bool enabled = false;
@@ -196,7 +196,6 @@ struct SearchCtx {
     uint64_t tile_cap = 0, spec_tiles = 0;
     bool spec_fill = false;
     bool pending = false;
-    bool fused = false;             // the first half was the single-pass exact search (k_fused): nothing is left to do unless it aborted
 };
 
 struct kmx_result {
@@ -216,11 +215,6 @@ struct kmx_result {
     uint64_t* v_hit_off = nullptr; uint32_t* v_positions = nullptr; uint8_t* v_status = nullptr; uint8_t* v_kinds = nullptr;   // the current host view
     const uint64_t* m_base = nullptr; const uint64_t* m_words = nullptr; const uint32_t* m_ccnt = nullptr; const uint64_t* m_csrc = nullptr;   // ... and mask view
     // the latency path (k_small): queries in, complete result out through one page-locked block the kernel reads and writes
-    // the single-pass exact search (k_fused): counters + tile descriptors in one block; taken when the previous batch on
-    // this handle (through the general pipeline) held nothing but plain exact lookups
-    DevBuf fused_state;
-    bool fused_ok = false;
-    uint64_t prev_nq = 0, prev_hits = 0;
     HostBuf mailbox;
     bool small_valid = false;              // the result of the last search lives in the mailbox only (no device buffers were written)
     bool host_valid = false, host_masks_valid = false;
@@ -241,7 +235,7 @@ struct kmx_result {
     {
         size_t b = 0;
         for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
-                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff, &fused_state})
+                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
             b += d->cap;
         return b;
     }
@@ -249,7 +243,7 @@ struct kmx_result {
     void release()
     {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
-                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff, &fused_state})
+                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
             b->release();
         for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox})
             b->release();
@@ -1086,8 +1080,6 @@ kmx_status kmx_stats_reset(kmx_index* ix)
     return KMX_OK;
 }
 
-static kmx_status enqueue_general(kmx_result* r, kmx_index* ix, const uint8_t* qr, const uint64_t* qo, hipStream_t s);
-
 kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, const void* d_qoff, uint64_t nq,
                                    uint32_t flags, void* stream, kmx_result** inout)
 {
@@ -1144,57 +1136,6 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->prefix_list.ensure(nq * 4));
     HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(nq), kmx::lookup_blocks(nq)) * 8));
     HIP_TRY(r->ctr.ensure(KMX_CTR_COUNT * sizeof(unsigned long long)));
-    // Steady state of a stream of plain exact lookups (BASELINE configs 2, 4, 5): the whole search in one pass (k_fused).
-    // Attempted when the previous batch on this handle, through the general pipeline, held nothing else, the output buffer
-    // exists and every k of the index fits the 16-letter fast path; the pass itself checks what it assumed and aborts otherwise.
-    static const bool no_fused = getenv("KMX_NO_FUSED") != nullptr;
-    if (r->fused_ok && !no_fused && ix->rec32 && ix->h_header.kmax <= 16 && !(flags & KMX_SEARCH_COUNT_ONLY) && nq >= 4096 && r->out.cap >= 4 &&
-        r->prev_nq) {
-        int items = (r->prev_hits / r->prev_nq) >= 24 ? 1 : 2;
-        if (const char* e = getenv("KMX_FUSED_ITEMS")) items = atoi(e);
-        const uint64_t n_tiles = (nq + kmx::fused_tile_queries(items) - 1) / kmx::fused_tile_queries(items);
-        const size_t state_bytes = ((KMX_CTR_COUNT + n_tiles) * 8 + 15) & ~size_t(15);
-        if (n_tiles < 0x7FFFFFFFull && r->fused_state.ensure(state_bytes) == hipSuccess) {
-            kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
-                             r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
-                             r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
-            auto* state = r->fused_state.as<unsigned long long>();
-            HIP_TRY(hipMemsetAsync(state, 0, state_bytes, s));     // counters, ticket and every tile descriptor: one block, one memset
-            timed(ix, K_FUSED, s, [&] {
-                kmx::launch_fused(s, items, ix->d_index, ix->d_arena, qr, qo, nq, d, r->hit_off.as<uint64_t>(), r->out.as<uint32_t>(), r->out.cap / 4, state);
-            });
-            HIP_TRY(hipMemcpyAsync(r->h_ctr, state, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
-            r->ctx = SearchCtx{ix, qr, qo, s, 0, 0, false, true, true};
-            if (flags & KMX_SEARCH_ASYNC) {
-                if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
-                HIP_TRY(hipEventRecord(r->done, s));
-                r->pool = ix->pool;
-                std::lock_guard<std::mutex> lock(ix->pool->mu);
-                ix->pool->pending.push_back(r);
-                return KMX_OK;
-            }
-            return search_finish(r);
-        }
-        (void)hipGetLastError();
-    }
-    kmx_status st = enqueue_general(r, ix, qr, qo, s);
-    if (st != KMX_OK) return st;
-    if (flags & KMX_SEARCH_ASYNC) {
-        if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(r->done, s));
-        r->pool = ix->pool;                                  // (a handle made for another index keeps its buffers, changes pools)
-        std::lock_guard<std::mutex> lock(ix->pool->mu);
-        ix->pool->pending.push_back(r);
-        return KMX_OK;
-    }
-    return search_finish(r);
-}
-
-// First half of the general pipeline: lookup, scan and (steady state) the speculative fill, then the counter read-back.
-static kmx_status enqueue_general(kmx_result* r, kmx_index* ix, const uint8_t* qr, const uint64_t* qo, hipStream_t s)
-{
-    const uint64_t nq = r->nq;
-    const uint32_t flags = r->flags;
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
                      r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
@@ -1228,8 +1169,16 @@ static kmx_status enqueue_general(kmx_result* r, kmx_index* ix, const uint8_t* q
         });
     HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     // everything after the read-back lives in search_finish: right away, or (KMX_SEARCH_ASYNC) when the result is next touched
-    r->ctx = SearchCtx{ix, qr, qo, s, tile_cap, spec_tiles, spec_fill, true, false};
-    return KMX_OK;
+    r->ctx = SearchCtx{ix, qr, qo, s, tile_cap, spec_tiles, spec_fill, true};
+    if (flags & KMX_SEARCH_ASYNC) {
+        if (!r->done) HIP_TRY(hipEventCreateWithFlags(&r->done, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(r->done, s));
+        r->pool = ix->pool;                                  // (a handle made for another index keeps its buffers, changes pools)
+        std::lock_guard<std::mutex> lock(ix->pool->mu);
+        ix->pool->pending.push_back(r);
+        return KMX_OK;
+    }
+    return search_finish(r);
 }
 
 // Second half of a search: waits for the counters of the first half, then validates / fills / sorts whatever the
@@ -1247,34 +1196,12 @@ static kmx_status search_finish(kmx_result* r)
     const uint8_t* qr = r->ctx.qr;
     const uint64_t* qo = r->ctx.qo;
     hipStream_t s = r->ctx.s;
-    const uint64_t nq = r->nq;
+    const uint64_t nq = r->nq, tile_cap = r->ctx.tile_cap, spec_tiles = r->ctx.spec_tiles;
     const uint32_t flags = r->flags;
+    const bool spec_fill = r->ctx.spec_fill;
     HIP_TRY(hipSetDevice(r->device));
     if (r->done && (flags & KMX_SEARCH_ASYNC)) HIP_TRY(hipEventSynchronize(r->done));
     else HIP_TRY(hipStreamSynchronize(s));
-    if (r->ctx.fused) {
-        r->ctx.fused = false;
-        if (r->h_ctr[KMX_CTR_FUSED_ABORT] == 0) {               // the pass held: everything is in place
-            r->n_error = r->h_ctr[KMX_CTR_ERROR];
-            r->n_none = r->h_ctr[KMX_CTR_NONE];
-            r->n_stitch = r->n_prefix = r->n_mask_words = 0;
-            r->n_exact = nq - r->n_error - r->n_none;
-            r->n_hits = r->h_ctr[KMX_CTR_TOTAL_HITS];
-            r->last_had_stitch = false;
-            r->prev_nq = nq; r->prev_hits = r->n_hits;
-            return KMX_OK;
-        }
-        // a query that is no plain exact lookup, or hit lists beyond the buffer: the general pipeline, from the start
-        r->fused_ok = false;
-        if (r->h_ctr[KMX_CTR_FUSED_ABORT] & 2) HIP_TRY(r->out.ensure(std::max<uint64_t>(r->h_ctr[KMX_CTR_TOTAL_HITS], 1) * 4));
-        r->flags = flags & ~KMX_SEARCH_ASYNC;
-        kmx_status gs = enqueue_general(r, ix, qr, qo, s);
-        if (gs != KMX_OK) return gs;
-        r->ctx.pending = false;
-        HIP_TRY(hipStreamSynchronize(s));
-    }
-    const uint64_t tile_cap = r->ctx.tile_cap, spec_tiles = r->ctx.spec_tiles;
-    const bool spec_fill = r->ctx.spec_fill;
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
                      r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
@@ -1319,8 +1246,6 @@ static kmx_status search_finish(kmx_result* r)
         HIP_TRY(hipStreamSynchronize(s));
     }
     r->n_hits = r->h_ctr[KMX_CTR_TOTAL_HITS];
-    r->fused_ok = r->n_stitch == 0 && r->n_prefix == 0;          // a stream of plain exact lookups: the next batch may take the single pass
-    r->prev_nq = nq; r->prev_hits = r->n_hits;
     if (flags & KMX_SEARCH_COUNT_ONLY) return KMX_OK;
 
     const uint64_t total = r->n_hits;

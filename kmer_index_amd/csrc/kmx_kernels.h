@@ -30,10 +30,6 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
 // the whole search of a small batch in one launch; `mailbox` is page-locked host memory (layout: kmx_types.h)
 void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags);
-// the single-pass exact search (k_fused): queries per tile for `items` in {1, 2, 4}
-uint64_t fused_tile_queries(int items);
-void launch_fused(hipStream_t s, int items, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
-                  const QueryDesc& d, uint64_t* hit_off, uint32_t* out, uint64_t out_cap, unsigned long long* state /* counters + descriptors */);
 uint64_t scan_blocks(uint64_t n);
 void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, uint32_t shift, uint32_t n_dir, uint32_t* d_dir);
 // cells of a dense element (KmxElemDev::cnt8): d_region = the element's contiguous copy, d_cells = cell 0

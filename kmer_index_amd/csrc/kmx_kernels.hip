@@ -1972,330 +1972,6 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
 }
 
 // ---------------------------------------------------------------------------
-// k_fused — the whole exact-match search in ONE pass: rank-hash + probe (kmer_index.hpp:56-84), offsets of the hit lists,
-// materialised lists (kmer_index_result.hpp:244-260).  For batches of plain exact lookups (every query's length is a k of
-// the index, the steady state of BASELINE configs 2, 4 and 5) it replaces k_lookup -> k_scan -> k_fill: the descriptors a
-// lookup produces (bucket, size) never leave the registers of the thread that probed, so the pass reads a query once and a
-// bucket once and writes an offset and the hits — no descriptor arrays, no second read of offsets, two launches less.
-//
-// A workgroup = a tile of 256 * ITEMS consecutive queries (tiles are numbered by a ticket, in the order the workgroups
-// start, so a tile only ever waits for tiles that are running or done):
-//   1. lookups, the thread's queries interleaved as in k_lookup;
-//   2. the tile's hit total is PUBLISHED (status "aggregate"), then wave 0 looks back over the descriptors of the tiles in
-//      front — decoupled look-back: sums aggregates until it meets an inclusive prefix — and publishes the tile's own
-//      inclusive prefix.  A descriptor is one 8-byte word that carries its own status, written and polled with relaxed
-//      agent-scope atomics (the data is the flag: no fences; the L2s of the eight XCDs are not coherent for plain accesses);
-//   3. hit_off of the tile's queries = exclusive prefix + scan inside the workgroup;
-//   4. the copy, k_fill's way: rounds of KMX_FUSED_SLOTS output slots — every query that owns slots of the round leaves ONE
-//      LDS word at its first slot, a "last non-zero word" scan hands every slot its owner, 12 independent buffer_load
-//      gathers per thread, coalesced non-temporal stores.
-// A query that is not a plain exact lookup (another length: STITCH / PREFIX), an output buffer that turns out too small, or
-// a spin that runs out set KMX_CTR_FUSED_ABORT: the host then discards the pass and runs the general pipeline.
-// ---------------------------------------------------------------------------
-typedef KMX_GLOBAL unsigned long long gu64;
-#define KMX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
-#define KMX_FUSED_SPIN_LIMIT (1u << 22)   // polls of one descriptor before the pass gives up (each sleeps ~64 clocks: about 0.1 s)
-
-template <int ITEMS>
-__global__ __launch_bounds__(KMX_BLOCK) void k_fused(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
-                                                     const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff, uint64_t nq,
-                                                     QueryDesc d, uint64_t* __restrict__ hit_off, uint32_t* __restrict__ out,
-                                                     uint64_t out_cap, unsigned long long* __restrict__ state)
-{
-    constexpr int S = KMX_FUSED_SLOTS, E = S / KMX_BLOCK;
-    constexpr uint64_t T = uint64_t(KMX_BLOCK) * ITEMS;
-    __shared__ KmxElemDev elems_s[KMX_MAX_KS];
-    __shared__ __attribute__((aligned(16))) uint32_t word[S];
-    __shared__ uint32_t wave_tot[KMX_BLOCK / KMX_WAVE];
-    __shared__ uint64_t s_tile, s_prefix;
-    __shared__ unsigned int s_none, s_err, s_bad;
-    unsigned long long* __restrict__ ctr = state;
-    gu64* desc = (gu64*)(state + KMX_CTR_COUNT);
-    const uint32_t tid = threadIdx.x, lane = lane_id(), wv = tid / KMX_WAVE;
-
-    if (tid == 0) {
-        s_tile = atomicAdd(&ctr[KMX_CTR_FUSED_TICKET], 1ull);
-        s_none = s_err = s_bad = 0;
-    }
-    {
-        const uint32_t n_words = ix->n_ks * uint32_t(sizeof(KmxElemDev) / 8);
-        const uint64_t* __restrict__ srcw = reinterpret_cast<const uint64_t*>(ix->elems);
-        uint64_t* dstw = reinterpret_cast<uint64_t*>(elems_s);
-        for (uint32_t i = tid; i < n_words; i += KMX_BLOCK) dstw[i] = srcw[i];
-    }
-    const uint8_t* __restrict__ qend = qranks + qoff[nq];
-    __syncthreads();
-    const uint64_t tile = s_tile;
-    const uint64_t qbase = tile * T;
-    if (qbase >= nq) return;                                            // (the grid is exactly ceil(nq / T) workgroups: never taken)
-
-    // ---- 1. lookups: all offsets, then all plan entries, then all letters, then all probes (one round trip per phase)
-    uint32_t src[ITEMS], cnt[ITEMS];                                    // (32-bit arena indices: the host takes this path for arenas < 2^31 entries)
-    {
-        const uint32_t sigma = ix->sigma, range = ix->range;
-        const uint8_t* __restrict__ dummy = reinterpret_cast<const uint8_t*>(ix);
-        uint64_t qb[ITEMS], hs[ITEMS];
-        uint32_t qm[ITEMS], praw[ITEMS];
-        u32x4_a1 w[ITEMS], pr[ITEMS];
-        bool plain[ITEMS], rok[ITEMS];
-        unsigned int n_none = 0, n_err = 0, n_bad = 0;
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const uint64_t q = qbase + uint64_t(it) * KMX_BLOCK + tid;
-            const uint64_t qq = q < nq ? q : nq - 1;
-            qb[it] = qoff[qq];
-            const uint64_t mlen = qoff[qq + 1] - qb[it];
-            qm[it] = mlen > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(mlen);
-        }
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) praw[it] = ((const KMX_GLOBAL uint32_t*)ix->plan)[min(qm[it], range - 1)];
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const uint64_t q = qbase + uint64_t(it) * KMX_BLOCK + tid;
-            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
-            // a plain exact lookup: one element serves the whole query, m == its k (:198-205; the multi-k scheme of such a length
-            // has one summand, :529-530, and is planned as SINGLE)
-            plain[it] = q < nq && qm[it] > 0 && qm[it] < range && (praw[it] & 0xFF) == KMX_SCHEME_SINGLE && el->k == qm[it] && qm[it] <= 16;
-            const bool wide = plain[it] && qranks + qb[it] + 16 <= qend;
-            w[it] = *reinterpret_cast<const u32x4_a1*>(wide ? qranks + qb[it] : dummy);
-            if (plain[it] && !wide) {                                   // the last letters of the buffer: byte loads
-                uint32_t t4[4] = {0, 0, 0, 0};
-                for (uint32_t j = 0; j < qm[it]; ++j) t4[j >> 2] |= uint32_t(qranks[qb[it] + j]) << ((j & 3) * 8);
-                w[it][0] = t4[0]; w[it][1] = t4[1]; w[it][2] = t4[2]; w[it][3] = t4[3];
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
-            uint64_t lo = uint64_t(w[it][0]) | (uint64_t(w[it][1]) << 32), hi = uint64_t(w[it][2]) | (uint64_t(w[it][3]) << 32);
-            uint64_t acc = 0;
-            bool ok = true;
-            const uint32_t len = plain[it] ? qm[it] : 0u;
-            for (uint32_t j = 0; j < len; ++j) {                        // Horner: sum r_i sigma^(k-i-1), :56-73
-                const uint32_t r = uint32_t(lo & 0xFF);
-                lo = (lo >> 8) | (hi << 56);
-                hi >>= 8;
-                ok &= r < sigma;
-                acc = acc * sigma + r;
-            }
-            hs[it] = acc;
-            rok[it] = ok;
-            const char* addr = reinterpret_cast<const char*>(dummy);
-            if (plain[it] && ok) {
-                if (el->table_kind == KMX_TABLE_DENSE)
-                    addr = el->cnt8 ? reinterpret_cast<const char*>(el->cnt8 + (acc & ~uint64_t(15)))
-                                    : reinterpret_cast<const char*>((el->atab ? el->atab : el->offs) + acc);
-                else
-                    addr = reinterpret_cast<const char*>(el->slots + slot_hash_dev(acc, el->log2cap));
-            }
-            pr[it] = *(const KMX_GLOBAL u32x4_a1*)addr;
-        }
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            const uint64_t q = qbase + uint64_t(it) * KMX_BLOCK + tid;
-            src[it] = 0; cnt[it] = 0;
-            if (q >= nq) continue;
-            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
-            uint8_t status = KMX_Q_OK;
-            uint64_t s64 = 0;
-            uint32_t c = 0;
-            if (!plain[it]) {
-                // not a plain exact lookup: errors are final (the general path reports the same), anything else voids the pass
-                if (qm[it] == 0) status = KMX_Q_EMPTY_QUERY;            // :195
-                else if (qm[it] >= range) status = KMX_Q_TOO_LONG;      // :507-509
-                else n_bad = 1;
-            } else if (!rok[it]) {
-                status = KMX_Q_BAD_RANK;
-            } else if (el->table_kind == KMX_TABLE_DENSE) {
-                if (el->cnt8) {
-                    const uint32_t b = uint32_t(hs[it]) & 15u;
-                    const uint32_t wsel = (b >> 2) == 0 ? pr[it][0] : (b >> 2) == 1 ? pr[it][1] : (b >> 2) == 2 ? pr[it][2] : pr[it][3];
-                    const uint32_t c8 = (wsel >> ((b & 3u) * 8u)) & 0xFFu;
-                    if (c8 != 255u) { s64 = el->cell_base + (hs[it] << el->cell_shift); c = c8; }
-                    else {
-                        const KMX_GLOBAL uint32_t* offs = as_global(el->offs);
-                        const uint32_t a = offs[hs[it]], b2 = offs[hs[it] + 1];
-                        s64 = el->arena_base + a; c = b2 - a;
-                    }
-                }
-                else if (el->atab) { s64 = el->arena_base + (pr[it][0] & ~31u); c = atab_count(pr[it][0], pr[it][1]); }
-                else { s64 = el->arena_base + pr[it][0]; c = pr[it][1] - pr[it][0]; }
-            } else {
-                const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);  // linear probing continues from the prefetched slot (:76-84)
-                const uint64_t mask = (uint64_t(1) << el->log2cap) - 1;
-                uint64_t sl = slot_hash_dev(hs[it], el->log2cap);
-                uint64_t key = uint64_t(pr[it][0]) | (uint64_t(pr[it][1]) << 32);
-                uint32_t off = pr[it][2], cc = pr[it][3];
-                while (cc != 0 && key != hs[it]) {
-                    sl = (sl + 1) & mask;
-                    const u64x2 raw = *(const KMX_GLOBAL u64x2*)(slots + sl);
-                    key = raw.x; off = uint32_t(raw.y); cc = uint32_t(raw.y >> 32);
-                }
-                if (cc) { s64 = el->arena_base + off; c = cc; }
-            }
-            n_err += status != KMX_Q_OK;
-            n_none += status == KMX_Q_OK && !c && plain[it];
-            src[it] = uint32_t(s64); cnt[it] = c;
-            d.kind[q] = c ? KMX_KIND_EXACT : KMX_KIND_NONE;
-            d.status[q] = status;
-        }
-        if (n_err) atomicAdd(&s_err, n_err);
-        if (n_none) atomicAdd(&s_none, n_none);
-        if (n_bad) atomicOr(&s_bad, 1u);
-    }
-
-    // ---- 2. + 3. offsets: scan inside the workgroup (query order = row by row), the tile's total, look-back, hit_off
-    uint64_t ex[ITEMS];
-    uint64_t tile_total = 0;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        uint64_t row_total;
-        ex[it] = tile_total + block_exclusive_scan_u64(cnt[it], &row_total);
-        tile_total += row_total;
-    }
-    if (wv == 0) {
-        if (lane == 0) __hip_atomic_store(desc + tile, (tile == 0 ? KMX_FUSED_PREFIX : KMX_FUSED_AGG) | tile_total, KMX_RLX_AGENT);
-        uint64_t excl = 0;
-        bool gave_up = false;
-        for (int64_t j = int64_t(tile) - 1; j >= 0; j -= KMX_WAVE) {    // 64 predecessors per round, the nearest in lane 0
-            const int64_t idx = j - int64_t(lane);
-            unsigned long long wd = KMX_FUSED_PREFIX;                    // in front of tile 0: an inclusive prefix of 0
-            if (idx >= 0) {
-                unsigned int spins = 0;
-                for (;;) {
-                    wd = __hip_atomic_load(desc + idx, KMX_RLX_AGENT);
-                    if (wd >> 62) break;
-                    if (++spins > KMX_FUSED_SPIN_LIMIT) { gave_up = true; wd = KMX_FUSED_PREFIX; break; }
-                    __builtin_amdgcn_s_sleep(1);
-                }
-            }
-            const uint64_t is_prefix = __ballot((wd >> 62) == 2);
-            const int first = is_prefix ? __ffsll((unsigned long long)is_prefix) - 1 : KMX_WAVE;
-            uint64_t v = int(lane) <= first ? KMX_FUSED_VALUE(wd) : 0;  // aggregates up to (and including) the nearest prefix
-            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
-            excl += v;
-            if (is_prefix) break;
-        }
-        if (__any(gave_up)) { if (lane == 0) atomicOr(&ctr[KMX_CTR_FUSED_ABORT], 4ull); }
-        if (lane == 0) {
-            if (tile != 0) __hip_atomic_store(desc + tile, KMX_FUSED_PREFIX | (excl + tile_total), KMX_RLX_AGENT);
-            s_prefix = excl;
-        }
-    }
-    __syncthreads();
-    const uint64_t prefix = s_prefix;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const uint64_t q = qbase + uint64_t(it) * KMX_BLOCK + tid;
-        if (q < nq) hit_off[q] = prefix + ex[it];
-    }
-    const bool last_tile = qbase + T >= nq;
-    if (tid == 0) {
-        if (last_tile) { hit_off[nq] = prefix + tile_total; ctr[KMX_CTR_TOTAL_HITS] = prefix + tile_total; }
-        if (s_err) atomicAdd(&ctr[KMX_CTR_ERROR], (unsigned long long)s_err);
-        if (s_none) atomicAdd(&ctr[KMX_CTR_NONE], (unsigned long long)s_none);
-        if (s_bad) atomicOr(&ctr[KMX_CTR_FUSED_ABORT], 1ull);
-    }
-    if (prefix + tile_total > out_cap) {                                // the buffer kept from the previous batch is too small
-        if (tid == 0) atomicOr(&ctr[KMX_CTR_FUSED_ABORT], 2ull);
-        return;
-    }
-    if (s_bad) return;                                                  // (the pass is void anyway)
-
-    // ---- 4. the copy, in rounds of S output slots of the tile's range [prefix, prefix + tile_total)
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint32_t*>(arena), 0, int(uint32_t(ix->arena_elems * 4 + 64)), 0x00020000);
-    // The rounds are laid over ABSOLUTE output slots from a 256-byte boundary on (the tile's first slots may lie before its
-    // own range: dead), so that every wave store covers whole 128-byte lines; only the two ends of a tile write partial lines.
-    const uint32_t lead = uint32_t(prefix & 63);
-    uint32_t* __restrict__ obase = out + (prefix - lead);
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) ex[it] += lead;
-    const uint64_t span = tile_total + lead;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    for (uint64_t sbase = 0; sbase < span; sbase += S) {
-        const uint64_t send = min(sbase + uint64_t(S), span);
-        {
-            u32x4* w4 = reinterpret_cast<u32x4*>(word) + tid * (E / 4);
-#pragma unroll
-            for (int j = 0; j < E / 4; ++j) w4[j] = u32x4(0);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) {
-            // the query owns slots [ex, ex + cnt) of the tile: the part inside this round starts at max(ex, sbase)
-            if (cnt[it] && ex[it] < send && ex[it] + cnt[it] > sbase) {
-                const uint32_t slot = ex[it] > sbase ? uint32_t(ex[it] - sbase) : 0u;
-                word[slot] = src[it] + uint32_t(sbase + slot - ex[it]) + uint32_t(S - slot);     // arena index of the slot's element + (S - slot): >= 1
-            }
-        }
-        __syncthreads();
-        {   // "last non-zero word so far" scan in blocked arrangement (as k_fill)
-            uint32_t v[E];
-            u32x4* w4 = reinterpret_cast<u32x4*>(word) + tid * (E / 4);
-#pragma unroll
-            for (int j = 0; j < E / 4; ++j) {
-                const u32x4 t = w4[j];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) v[4 * j + i] = t[i];
-            }
-            uint32_t last = 0;
-#pragma unroll
-            for (int j = 0; j < E; ++j) last = v[j] ? v[j] : last;
-            const uint64_t has = __ballot(last != 0);
-            const uint64_t below = has & ((uint64_t(1) << lane) - 1);
-            const int srcl = below ? 63 - __clzll(below) : 0;
-            uint32_t carry = __shfl(last, srcl);
-            if (!below) carry = 0;
-            if (lane == KMX_WAVE - 1) wave_tot[wv] = last ? last : carry;
-            __syncthreads();
-            uint32_t wcarry = 0;
-#pragma unroll
-            for (uint32_t i = 0; i < KMX_BLOCK / KMX_WAVE; ++i) {
-                const uint32_t t = wave_tot[i];
-                if (i < wv && t) wcarry = t;
-            }
-            uint32_t run = carry ? carry : wcarry;
-#pragma unroll
-            for (int j = 0; j < E; ++j) { run = v[j] ? v[j] : run; v[j] = run; }
-#pragma unroll
-            for (int j = 0; j < E / 4; ++j) {
-                u32x4 t;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) t[i] = v[4 * j + i];
-                w4[j] = t;
-            }
-        }
-        __syncthreads();
-        uint32_t val[E];
-#pragma unroll
-        for (int j = 0; j < E; ++j) {                                   // branch-free: all E loads in flight before the first store
-            const uint32_t slot = j * KMX_BLOCK + tid;
-            const bool live = sbase + slot < send && sbase + slot >= lead;
-            const uint32_t wvd = word[slot];
-            const uint32_t boff = live ? ((wvd - uint32_t(S) + slot) << 2) : 0u;
-            val[j] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, boff, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-            const uint32_t slot = j * KMX_BLOCK + tid;
-            if (sbase + slot < send && sbase + slot >= lead) __builtin_nontemporal_store(val[j], obase + sbase + slot);
-        }
-        __syncthreads();                                                // word[] is cleared again by the next round
-    }
-}
-
-uint64_t fused_tile_queries(int items) { return uint64_t(KMX_BLOCK) * (items >= 4 ? 4 : items >= 2 ? 2 : 1); }
-
-void launch_fused(hipStream_t s, int items, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
-                  const QueryDesc& d, uint64_t* hit_off, uint32_t* out, uint64_t out_cap, unsigned long long* state)
-{
-    const dim3 grid((unsigned int)((nq + fused_tile_queries(items) - 1) / fused_tile_queries(items))), block(KMX_BLOCK);
-    if (items >= 4) hipLaunchKernelGGL(k_fused<4>, grid, block, 0, s, ix, arena, qranks, qoff, nq, d, hit_off, out, out_cap, state);
-    else if (items >= 2) hipLaunchKernelGGL(k_fused<2>, grid, block, 0, s, ix, arena, qranks, qoff, nq, d, hit_off, out, out_cap, state);
-    else hipLaunchKernelGGL(k_fused<1>, grid, block, 0, s, ix, arena, qranks, qoff, nq, d, hit_off, out, out_cap, state);
-}
-
-// ---------------------------------------------------------------------------
 // k_compact — STITCH queries: decode the mask words and compact the surviving
 // candidates (is_valid + push_back of kmer_index_result.hpp:250-256) with a
 // popcount prefix per word.  One wave per query; candidates are ascending, so

@@ -146,14 +146,5 @@ enum {
     KMX_CTR_PREFIX_BIG = 11,  // PREFIX queries that are not 'small' (listed from the BACK of prefix_list)
     KMX_CTR_STITCH_TINY = 12, // STITCH queries with at most KMX_VTINY candidates and filter-bucket entries (listed from the BACK of stitch_list)
     KMX_CTR_STITCH_RESOLVED = 13, // STITCH queries k_lookup resolved by itself (tiny first bucket, survivors one run of it)
-    KMX_CTR_FUSED_TICKET = 14,    // k_fused: next tile (tiles are numbered in the order their workgroups start)
-    KMX_CTR_FUSED_ABORT = 15,     // k_fused: != 0 — the batch is not for the fused pass (bit 0: a query that is not a plain exact lookup,
-                                  // bit 1: the hit lists outgrow the output buffer, bit 2: a look-back spin ran out): the result is void
     KMX_CTR_COUNT = 16
 };
-// k_fused's tile descriptors follow the counter block in one allocation (zeroed by ONE memset per launch): one u64 per tile,
-// [63:62] status (0 not yet, 1 the tile's own hit count, 2 the inclusive prefix: hits of all tiles up to and including it), [61:0] value
-#define KMX_FUSED_AGG (1ull << 62)
-#define KMX_FUSED_PREFIX (2ull << 62)
-#define KMX_FUSED_VALUE(w) ((w) & ((1ull << 62) - 1))
-#define KMX_FUSED_SLOTS 3072      // output slots per gather round (k_fill's tile)

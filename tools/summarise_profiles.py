@@ -77,8 +77,7 @@ def main():
         for row in csv.DictReader(f):
             if row["Counter_Name"] == "FETCH_SIZE" and "k_scan_reduce" in row["Kernel_Name"] and float(row["Counter_Value"]) > red:
                 red, red_items = float(row["Counter_Value"]), int(row["Grid_Size"]) // 256 * 4096
-    dom_short = bench["roofline"].get("kernel", "k_fill")           # k_fused when the steady state took the single pass
-    fill = max((k for k in kernels if k.startswith(f"kmx::{dom_short}<")), key=lambda k: kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches"])
+    fill = max((k for k in kernels if k.startswith("kmx::k_fill<")), key=lambda k: kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches"])
     out = {
         "source": f"tools/profile_round.sh {a.tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
                   "--kernel-trace --stats, each over `python3 bench.py" + (f" --config {a.config}" if a.config != 2 else "") + " --no-cpu-baseline --no-open-compare --steps 8 --warmup 2`, MI355X",
@@ -88,7 +87,7 @@ def main():
         "bench_value_M_queries_per_s": bench["value"],
         "kernels": kernels,
         "calibration_scan_reduce_fetch_ratio": round(red * 1024 / (4.0 * max(red_items, 1)), 4),
-        "dominant": {
+        "k_fill": {
             "kernel": fill,
             "hbm_bytes_per_launch": kernels[fill]["hbm_bytes_per_launch"],
             "fetch_bytes_corrected": kernels[fill]["fetch_bytes_corrected"],
@@ -98,11 +97,10 @@ def main():
             "avg_launch_ms_bench_hip_events": bench["roofline"]["avg_launch_ms"],
         },
     }
-    out["k_fill"] = out["dominant"]          # (the key earlier summaries used)
     for name in (f"{a.round}_pmc_summary_{a.tag}.json", f"pmc_summary_current{sfx}.json"):
         with open(os.path.join(dst, name), "w") as f:
             json.dump(out, f, indent=1)
-    print(json.dumps(out["dominant"], indent=1))
+    print(json.dumps(out["k_fill"], indent=1))
     print("calibration ratio (expect ~0.50):", out["calibration_scan_reduce_fetch_ratio"])
 
 
