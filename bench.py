@@ -383,8 +383,9 @@ def worker(args):
             oidx = orc.Index(text, args.sigma, ks, n_threads=T)
             log(f"oracle (CPU restatement) index built in {time.time() - t1:.1f}s")
             ns = min(args.cpu_sample, nq)
+            ref_pool = orc.ref_lib() is not None and hasattr(orc.ref_lib(), "ref_pool_run")   # the REFERENCE's thread_pool.cpp, built in oracle/_ref
             t1 = time.perf_counter()
-            oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=T, keep_hits=False)
+            oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=T, keep_hits=False, reference_pool=ref_pool)
             dt = time.perf_counter() - t1
             n1 = min(ns, 1_000_000)                               # the same restatement on one thread ("also T=1")
             t1 = time.perf_counter()
@@ -397,9 +398,10 @@ def worker(args):
             except Exception:
                 pass
             cpu_baseline = {"value": round(ns / dt / 1e6, 4), "unit": "M queries/s", "cores": T, "kind": "port",
-                            "sample": f"first {ns} of the {nq} queries, same 1e8-bp text, search(q).to_vector() per query "
-                                      f"on the oracle's thread pool ({T} threads of {usable} usable, {cpu_model}; "
-                                      f"std::unordered_map buckets), {dt:.1f}s wall",
+                            "sample": f"first {ns} of the {nq} queries, same 1e8-bp text, the restated search(q).to_vector() per query, tasks carried by "
+                                      + ("the reference's own thread_pool (thread_pool.{hpp,cpp} compiled from its sources into oracle/_ref)" if ref_pool
+                                         else "the restated thread pool (oracle/_ref not built)")
+                                      + f" ({T} threads of {usable} usable, {cpu_model}; std::unordered_map buckets in place of robin_hood), {dt:.1f}s wall",
                             "single_thread_value": round(n1 / dt1 / 1e6, 4), "single_thread_sample": f"first {n1} queries, {dt1:.1f}s"}
             o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))

@@ -583,9 +583,12 @@ int orc_search(const orc_index* p, const uint8_t* q, uint64_t m, int mode, uint3
 // runs search(q).to_vector() per query.  Pass 1 keeps the vectors, then hit_off
 // (nq+1) and one concatenated positions array (malloc'd) are produced.
 // keep_hits = 0 discards the vectors after folding them into *checksum (timing leg).
-int orc_search_batch(const orc_index* p, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
-                     int mode, uint32_t n_threads, int keep_hits, uint64_t* hit_off,
-                     uint32_t** positions, int32_t* status, uint64_t* checksum)
+// `runner` (may be NULL): an external pool that carries the chunk tasks — oracle/_ref's ref_pool_run, i.e. the REFERENCE's own
+// thread_pool.{hpp,cpp} compiled from its sources; NULL = the restated pool above.
+typedef void (*orc_pool_runner)(uint32_t n_threads, uint32_t n_tasks, void (*fn)(void*, uint32_t), void* ctx);
+int orc_search_batch_on(const orc_index* p, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
+                        int mode, uint32_t n_threads, int keep_hits, uint64_t* hit_off,
+                        uint32_t** positions, int32_t* status, uint64_t* checksum, orc_pool_runner runner)
 {
     const auto* idx = reinterpret_cast<const orc::index*>(p);
     std::vector<std::vector<uint32_t>> hits(keep_hits ? nq : 0);
@@ -593,29 +596,31 @@ int orc_search_batch(const orc_index* p, const uint8_t* qranks, const uint64_t* 
     uint32_t T = std::max<uint32_t>(n_threads, 1);
     uint64_t n_chunks = std::max<uint64_t>(1, std::min<uint64_t>(nq, uint64_t(4) * T));
     std::vector<uint64_t> sums(n_chunks, 0);
-    {
+    auto chunk = [&](uint64_t c) {
+        const uint64_t b = nq * c / n_chunks, e = nq * (c + 1) / n_chunks;
+        uint64_t sum = 0;
+        for (uint64_t i = b; i < e; ++i) {
+            int st = orc::ST_OK;
+            std::vector<uint32_t> v;
+            try {
+                v = idx->search(qranks + qoff[i], qoff[i + 1] - qoff[i], mode).to_vector();
+            } catch (const orc::search_error& err) {
+                st = err.status;
+            }
+            if (status) status[i] = st;
+            counts[i] = v.size();
+            for (uint32_t x : v) sum = sum * 1099511628211ull + x + 1;
+            if (keep_hits) hits[i] = std::move(v);
+        }
+        sums[c] = sum;
+    };
+    if (runner) {
+        using chunk_t = decltype(chunk);
+        runner(T, uint32_t(n_chunks), [](void* ctx, uint32_t c) { (*static_cast<chunk_t*>(ctx))(c); }, &chunk);
+    } else {
         orc::thread_pool pool(T);
         std::vector<std::future<void>> futs;
-        for (uint64_t c = 0; c < n_chunks; ++c) {
-            uint64_t b = nq * c / n_chunks, e = nq * (c + 1) / n_chunks;
-            futs.push_back(pool.execute([&, b, e, c] {
-                uint64_t sum = 0;
-                for (uint64_t i = b; i < e; ++i) {
-                    int st = orc::ST_OK;
-                    std::vector<uint32_t> v;
-                    try {
-                        v = idx->search(qranks + qoff[i], qoff[i + 1] - qoff[i], mode).to_vector();
-                    } catch (const orc::search_error& err) {
-                        st = err.status;
-                    }
-                    if (status) status[i] = st;
-                    counts[i] = v.size();
-                    for (uint32_t x : v) sum = sum * 1099511628211ull + x + 1;
-                    if (keep_hits) hits[i] = std::move(v);
-                }
-                sums[c] = sum;
-            }));
-        }
+        for (uint64_t c = 0; c < n_chunks; ++c) futs.push_back(pool.execute([&chunk, c] { chunk(c); }));
         for (auto& f : futs) f.get();
     }
     uint64_t total = 0;
@@ -628,6 +633,13 @@ int orc_search_batch(const orc_index* p, const uint8_t* qranks, const uint64_t* 
         for (uint64_t i = 0; i < nq; ++i) { std::copy(hits[i].begin(), hits[i].end(), *positions + o); o += hits[i].size(); }
     }
     return 0;
+}
+
+int orc_search_batch(const orc_index* p, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
+                     int mode, uint32_t n_threads, int keep_hits, uint64_t* hit_off,
+                     uint32_t** positions, int32_t* status, uint64_t* checksum)
+{
+    return orc_search_batch_on(p, qranks, qoff, nq, mode, n_threads, keep_hits, hit_off, positions, status, checksum, nullptr);
 }
 
 // Ground truth: every offset p with text[p..p+m) == q, ascending (what the

@@ -54,6 +54,8 @@ def lib():
         L.orc_search_batch.restype = C.c_int
         L.orc_search_batch.argtypes = [C.c_void_p, _u8p, _u64p, C.c_uint64, C.c_int, C.c_uint32, C.c_int,
                                        C.c_void_p, C.POINTER(C.c_void_p), C.c_void_p, C.POINTER(C.c_uint64)]
+        L.orc_search_batch_on.restype = C.c_int
+        L.orc_search_batch_on.argtypes = L.orc_search_batch.argtypes + [C.c_void_p]
         L.orc_naive_scan.restype = C.c_uint64
         L.orc_naive_scan.argtypes = [_u8p, C.c_uint64, _u8p, C.c_uint64, _u32p, C.c_uint64]
         L.orc_naive_batch.restype = C.c_uint64
@@ -162,8 +164,10 @@ class Index:
         words = _take(mw.value, mb.value // 64 + 1, np.uint64) if mw.value else np.zeros(0, np.uint64)
         return st, out, {"words": words, "bits": int(mb.value), "bypass": bool(byp.value), "candidates": int(nc.value)}
 
-    def search_batch(self, qranks, qoff, mode=MODE_INTENDED, n_threads=1, keep_hits=True):
-        """Thread-pool batch.  Returns (hit_off, positions, status, checksum)."""
+    def search_batch(self, qranks, qoff, mode=MODE_INTENDED, n_threads=1, keep_hits=True, reference_pool=False):
+        """Thread-pool batch.  Returns (hit_off, positions, status, checksum).
+        reference_pool: carry the chunk tasks on the REFERENCE's own thread_pool (oracle/_ref, built from its
+        thread_pool.{hpp,cpp}) instead of the restated pool; raises when oracle/_ref is not built."""
         qranks = np.ascontiguousarray(qranks, np.uint8)
         qoff = np.ascontiguousarray(qoff, np.uint64)
         nq = qoff.size - 1
@@ -172,8 +176,15 @@ class Index:
         pos = C.c_void_p()
         cks = C.c_uint64()
         qq = qranks if qranks.size else np.zeros(1, np.uint8)
-        lib().orc_search_batch(self._h, qq, qoff, nq, mode, n_threads, int(keep_hits), hit_off.ctypes.data,
-                               C.byref(pos), status.ctypes.data, C.byref(cks))
+        if reference_pool:
+            R = ref_lib()
+            if R is None or not hasattr(R, "ref_pool_run"):
+                raise RuntimeError("oracle/_ref/libref.so (the reference's thread_pool) is not built")
+            lib().orc_search_batch_on(self._h, qq, qoff, nq, mode, n_threads, int(keep_hits), hit_off.ctypes.data,
+                                      C.byref(pos), status.ctypes.data, C.byref(cks), C.cast(R.ref_pool_run, C.c_void_p))
+        else:
+            lib().orc_search_batch(self._h, qq, qoff, nq, mode, n_threads, int(keep_hits), hit_off.ctypes.data,
+                                   C.byref(pos), status.ctypes.data, C.byref(cks))
         positions = _take(pos.value, hit_off[nq], np.uint32) if keep_hits else np.zeros(0, np.uint32)
         return hit_off, positions, status[:nq], int(cks.value)
 

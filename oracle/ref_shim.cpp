@@ -75,4 +75,16 @@ uint64_t ref_pool_sum(uint32_t n_threads, uint32_t n_tasks)
     return sum.load();
 }
 
+// Runs fn(ctx, i) for i in [0, n_tasks) as n_tasks tasks of the reference's thread_pool (execute -> future, FIFO queue,
+// thread_pool.hpp:89-108 / thread_pool.cpp:12-53) and joins them: the carrier of the CPU baseline's batch
+// (the reference has no batch search of its own; this is the harness a user of its pool would write).
+void ref_pool_run(uint32_t n_threads, uint32_t n_tasks, void (*fn)(void*, uint32_t), void* ctx)
+{
+    kmer::detail::thread_pool pool(n_threads);
+    std::vector<std::future<void>> futs;
+    futs.reserve(n_tasks);
+    for (uint32_t i = 0; i < n_tasks; ++i) futs.emplace_back(pool.execute(fn, ctx, i));
+    for (auto& f : futs) f.get();
+}
+
 } // extern "C"

@@ -69,6 +69,19 @@ def test_thread_pool_of_real_reference(orc):
     assert R.ref_pool_sum(1, 10) == 55
 
 
+def test_batch_search_carried_by_the_reference_thread_pool(orc):
+    """The CPU baseline's batch (bench.py cpu_baseline) runs its chunk tasks on the REFERENCE's own thread_pool
+    (thread_pool.{hpp,cpp} from /root/reference in oracle/_ref): same result as on the restated pool."""
+    if orc.ref_lib() is None:
+        pytest.skip("oracle/_ref not built")
+    text = synth.ranks(3, 150_000, 4)
+    q, off = synth.mixed_queries(4, text, 30_000, [5, 8, 9, 17], 4)
+    idx = orc.Index(text, 4, [8])
+    a = idx.search_batch(q, off, n_threads=6)
+    b = idx.search_batch(q, off, n_threads=6, reference_pool=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+
+
 def test_planner_thesis_kat(orc):
     gold = json.load(open(os.path.join(GOLD, "planner.json")))
     multi, nk = orc.plan(gold["thesis"]["ks"])
