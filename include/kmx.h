@@ -80,8 +80,12 @@ typedef struct kmx_options {
     uint32_t keep_host_arena;  /* keep a host copy of the position arena (kmx_index_arena_host)         */
     uint32_t host_flatten;     /* 1 = build every element on host threads; 0 = on the device when the
                                   key space allows (sigma^k <= 2^26), host otherwise                     */
-    uint32_t no_aligned_copy;  /* 1 = do not keep the second, 128-byte-line-aligned copy of long buckets (saves
-                                  up to ~1.2x the position array; exact lookups then read ~13 % more)      */
+    uint32_t no_aligned_copy;  /* 1 = keep neither of the derived bucket layouts: the second, 128-byte-line-aligned copy of
+                                  long buckets (avg >= 32 positions; up to ~1.2x the position array, exact lookups read ~13 %
+                                  less with it) and the fixed-size cells + one-byte count table of short buckets (avg <= 24;
+                                  up to 8x the position array, +8...17 % queries/s on DNA5 k=10 / protein k=5).  Both are
+                                  also left out on their own when their offsets would not fit 32 bits (texts near 2^32
+                                  letters): kmx_index_info's device_bytes tells what an index really holds.          */
     /* ---- since KMX_VERSION 2 (a caller compiled against version 1 passes the shorter struct_size and gets one replica) ---- */
     uint32_t n_devices;        /* 0 / 1: one replica on `device`.  N > 1: the index is built once on devices[0] and its flat
                                   image replicated (device-to-device copies) into the HBM of devices[1..N-1]; a host-buffer
