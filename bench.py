@@ -47,7 +47,8 @@ def parse_args(argv=None):
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5],
                     help="BASELINE.json configs[N-1]; 2 = the metric's workload (default), 3/4/5 are informational")
-    ap.add_argument("--n", type=int, default=0, help="text length (0 = the config's)")
+    ap.add_argument("--n", "--text-len", dest="n", type=int, default=0,
+                    help="text length (0 = the config's); spell it --text-len under torch.distributed.run, whose own parser takes --n for an ambiguous prefix")
     ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (0 = the config's)")
     ap.add_argument("--table", choices=["open", "dense", "auto"], default="auto",
                     help="auto = the engine's default policy (direct addressing when sigma^k <= 4(n-k+1), else open addressing)")

@@ -8,7 +8,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SMALL = ["--n", "300000", "--nq", "40000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-open-compare"]
+SMALL = ["--text-len", "300000", "--nq", "40000", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-open-compare"]
 
 
 def _run(args, env_extra=None, timeout=600):
@@ -61,6 +61,23 @@ def test_two_ranks_spawned_by_bench_itself_rehearsal():
     g = out["gather_hits"]
     assert g["gathered_hits"] == out["config"]["total_hits_all_gpus"] and g["ms_per_step"] > 0 and g["bytes_per_peer_per_step"] > 0
     assert len(out["roofline"]["per_rank_frac"]) == 2
+
+
+@pytest.mark.gpu
+def test_two_ranks_under_the_distributed_launcher_rehearsal():
+    """The driver's launch form: `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` (RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* from the launcher); two ranks share the test box's GPU, so the exchange runs over gloo."""
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29587",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--oversubscribe"] + SMALL
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = next((l for l in p.stdout.splitlines()[::-1] if l.startswith("{")), None)
+    assert p.returncode == 0 and line, p.stderr[-2000:]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["verified_vs_oracle"] is True and out["rccl"]["ranks_seen"] == 2
+    assert out["gather_hits"]["gathered_hits"] == out["config"]["total_hits_all_gpus"]
 
 
 @pytest.mark.gpu
