@@ -173,6 +173,10 @@ uint64_t kmx_fast_pow(uint64_t base, uint8_t exp);
  *      ready for kmx_result_view. */
 kmx_status kmx_search_batch(const kmx_index* index, const uint8_t* qranks, const uint64_t* qoff,
                             uint64_t nq, uint32_t flags, kmx_result** out);
+/*      A batch whose descriptors or hit lists do not fit the device in one pass (more than 2^25 queries, or an out-of-memory
+ *      on the first attempt) is streamed through the device in chunks: every chunk's result is moved to host memory and the
+ *      device buffers serve the next chunk, a chunk that still does not fit is halved.  The result then has one part per
+ *      chunk (kmx_result_parts), its host views and counts are those of the whole batch, device views do not exist for it. */
 
 /* Device-buffer form: d_qranks / d_qoff are device pointers already resident in HBM (on an index with several replicas: in
  * the HBM of any of its devices — the replica on the device that owns d_qranks serves the call),

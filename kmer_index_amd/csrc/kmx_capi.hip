@@ -81,6 +81,14 @@ struct HostBuf {
         cap = p ? bytes + 64 : 0;
         return p != nullptr;
     }
+    bool ensure_pageable(size_t bytes)                      // plain malloc memory (chunk copies of a streamed batch: not worth pinning)
+    {
+        if (bytes <= cap && !pinned) return true;
+        release();
+        p = malloc(bytes + 64);
+        cap = p ? bytes + 64 : 0;
+        return p != nullptr;
+    }
     bool ensure_pinned(size_t bytes)                        // page-locked or nothing
     {
         if (bytes <= cap && pinned) return true;
@@ -230,6 +238,11 @@ struct kmx_result {
     std::vector<kmx_result*> parts;
     std::vector<uint64_t> part_q0;
     std::vector<uint64_t> part_w0;         // first mask word of each part in the merged mask view
+    // a batch too large for one pass (kmx_search_batch streams it through the device in chunks): the parts are host-resident
+    // copies of the chunks' results, `worker` is the one result whose device buffers served every chunk
+    bool chunked = false;                  // (parent) its parts are chunks
+    bool host_chunk = false;               // (part) lives in host memory only
+    kmx_result* worker = nullptr;
 
     size_t device_bytes() const
     {
@@ -1395,6 +1408,75 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
     return KMX_OK;
 }
 
+// A batch too large for one pass over the device (hard part 1: "chunked batches so output fits"): the queries go
+// through ONE worker result chunk by chunk; every chunk's result is copied to host memory of its own and the device buffers
+// serve the next chunk.  A chunk that still runs out of device memory is halved and tried again.  The parent presents the
+// chunks as one result through the merged views of multi-part results; device views do not exist for it.
+static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq, uint32_t flags,
+                                      kmx_result** out, uint64_t chunk_q)
+{
+    kmx_result* parent = *out;
+    if (parent && !parent->chunked) {                        // a plain handle from an earlier call: its buffers become the worker's
+        kmx_result* fresh = new kmx_result();
+        fresh->worker = parent;
+        parent = fresh;
+    }
+    if (!parent) parent = new kmx_result();
+    *out = parent;
+    parent->chunked = true;
+    for (kmx_result* p : parent->parts) kmx_result_free(p);
+    parent->parts.clear();
+    parent->part_q0.assign(1, 0);
+    parent->index = ix; parent->device = ix->device; parent->flags = flags & ~KMX_SEARCH_ASYNC; parent->nq = nq;
+    parent->host_valid = parent->host_masks_valid = false;
+    parent->n_hits = parent->n_exact = parent->n_stitch = parent->n_prefix = parent->n_error = parent->n_none = parent->n_mask_words = 0;
+    const bool masks = (flags & KMX_SEARCH_KEEP_MASKS) != 0;
+    chunk_q = std::max<uint64_t>(chunk_q, 1);
+    for (uint64_t q0 = 0; q0 < nq;) {
+        const uint64_t q1 = std::min(nq, q0 + chunk_q);
+        kmx_status st = search_host_one(ix, qranks, qoff, q0, q1, flags, &parent->worker, true);
+        if (st == KMX_ERR_OUT_OF_MEMORY && chunk_q > 1024) { chunk_q /= 2; (void)hipGetLastError(); continue; }
+        if (st != KMX_OK) return st;
+        kmx_result* w = parent->worker;
+        const uint64_t* ho; const uint32_t* pos; const uint8_t* stt; const uint8_t* kd;
+        st = kmx_result_view(w, &ho, &pos, &stt, &kd);
+        if (st == KMX_ERR_OUT_OF_MEMORY && chunk_q > 1024) { chunk_q /= 2; continue; }
+        if (st != KMX_OK) return st;
+        const uint64_t* mb = nullptr; const uint64_t* mw = nullptr; const uint32_t* cc = nullptr; const uint64_t* cs = nullptr;
+        if (masks && (st = kmx_result_masks(w, &mb, &mw, &cc, &cs)) != KMX_OK) return st;
+        const uint64_t cq = q1 - q0;
+        auto* part = new kmx_result();
+        parent->parts.push_back(part);
+        parent->part_q0.push_back(q1);
+        part->host_chunk = true; part->small_valid = true; part->host_valid = true; part->host_masks_valid = masks; part->quiesced = true;
+        part->device = ix->device; part->flags = parent->flags; part->nq = cq;
+        part->n_hits = w->n_hits; part->n_exact = w->n_exact; part->n_stitch = w->n_stitch; part->n_prefix = w->n_prefix;
+        part->n_error = w->n_error; part->n_none = w->n_none; part->n_mask_words = w->n_mask_words;
+        const bool have_pos = !(flags & KMX_SEARCH_COUNT_ONLY) && w->n_hits;
+        if (!part->h_hit_off.ensure_pageable((cq + 1) * 8) || !part->h_status.ensure_pageable(cq + 1) || !part->h_kinds.ensure_pageable(cq + 1) ||
+            !part->h_positions.ensure_pageable(have_pos ? w->n_hits * 4 : 4) ||
+            (masks && (!part->h_mask_base.ensure_pageable((cq + 1) * 8) || !part->h_cand_count.ensure_pageable((cq + 1) * 4) ||
+                       !part->h_cand_src.ensure_pageable((cq + 1) * 8) || !part->h_mask_words.ensure_pageable((w->n_mask_words + 1) * 8))))
+            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_search_batch: host allocation for a chunk failed");
+        memcpy(part->h_hit_off.p, ho, (cq + 1) * 8);
+        memcpy(part->h_status.p, stt, cq);
+        memcpy(part->h_kinds.p, kd, cq);
+        if (have_pos) memcpy(part->h_positions.p, pos, w->n_hits * 4);
+        part->v_hit_off = part->h_hit_off.as<uint64_t>(); part->v_positions = part->h_positions.as<uint32_t>();
+        part->v_status = part->h_status.as<uint8_t>(); part->v_kinds = part->h_kinds.as<uint8_t>();
+        if (masks) {
+            memcpy(part->h_mask_base.p, mb, cq * 8); memcpy(part->h_cand_count.p, cc, cq * 4); memcpy(part->h_cand_src.p, cs, cq * 8);
+            if (w->n_mask_words) memcpy(part->h_mask_words.p, mw, w->n_mask_words * 8);
+            part->m_base = part->h_mask_base.as<uint64_t>(); part->m_words = part->h_mask_words.as<uint64_t>();
+            part->m_ccnt = part->h_cand_count.as<uint32_t>(); part->m_csrc = part->h_cand_src.as<uint64_t>();
+        }
+        parent->n_hits += part->n_hits; parent->n_exact += part->n_exact; parent->n_stitch += part->n_stitch; parent->n_prefix += part->n_prefix;
+        parent->n_error += part->n_error; parent->n_none += part->n_none;
+        q0 = q1;
+    }
+    return KMX_OK;
+}
+
 kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
                             uint32_t flags, kmx_result** out)
 {
@@ -1406,8 +1488,18 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     kmx_index* ix = const_cast<kmx_index*>(cix);
     const size_t W = ix->n_replicas();
     if (W == 1) {
-        if (*out && !(*out)->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle belongs to a multi-device search");
-        return search_host_one(ix, qranks, qoff, 0, nq, flags, out, true);
+        if (*out && !(*out)->parts.empty() && !(*out)->chunked) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle belongs to a multi-device search");
+        uint64_t chunk_q = uint64_t(1) << 25;                   // queries per pass; KMX_HOST_CHUNK overrides (tests)
+        if (const char* e = getenv("KMX_HOST_CHUNK")) { const long long v = atoll(e); if (v > 0) chunk_q = uint64_t(v); }
+        if (nq > chunk_q || (*out && (*out)->chunked)) return search_host_chunked(ix, qranks, qoff, nq, flags, out, chunk_q);
+        const bool fresh = *out == nullptr;
+        kmx_status st = search_host_one(ix, qranks, qoff, 0, nq, flags, out, true);
+        if (st == KMX_ERR_OUT_OF_MEMORY && nq > 4096) {          // the batch does not fit the device in one pass: stream it
+            (void)hipGetLastError();
+            if (fresh && *out) { kmx_result_free(*out); *out = nullptr; }
+            return search_host_chunked(ix, qranks, qoff, nq, flags, out, std::max<uint64_t>(nq / 4, 1024));
+        }
+        return st;
     }
     // several replicas: replica r searches the contiguous range [nq*r/W, nq*(r+1)/W) on its own device and
     // stream; all of them are started before the first is waited for.  The parent result presents the parts as one.
@@ -1482,7 +1574,9 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
                                   const uint8_t** d_status)
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: result is NULL");
+    if (r->chunked) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: the batch was streamed through the device in chunks: its result lives in host memory only");
     if (!r->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: the result spans several devices: use kmx_result_part_view_device");
+    if (r->host_chunk) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: the batch was streamed through the device in chunks: its result lives in host memory only");
     if (r->small_valid) {
         // the last search ran on the latency path and left nothing in HBM: run the same queries (they are still in the
         // mailbox) through the device form now
@@ -1511,7 +1605,7 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
 {
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view: result is NULL");
     if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
-    if (!r->parts.empty() && !r->host_valid) {
+    if ((!r->parts.empty() || r->chunked) && !r->host_valid) {
         // the parts of a multi-device result, concatenated in replica order: every device copies straight into its slice
         // of the one host buffer (all links at once), the offsets are rebased on the host
         const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
@@ -1610,7 +1704,7 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
     if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: result is NULL");
     if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
     if (!(r->flags & KMX_SEARCH_KEEP_MASKS)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_masks: search ran without KMX_SEARCH_KEEP_MASKS");
-    if (!r->parts.empty() && !r->host_masks_valid) {
+    if ((!r->parts.empty() || r->chunked) && !r->host_masks_valid) {
         // per-part mask views, concatenated; a part's mask_base counts from its own first word, cand_src is an arena
         // index and the same in every replica
         uint64_t n_words = 0;
@@ -1665,9 +1759,11 @@ kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uin
 void kmx_result_free(kmx_result* r)
 {
     if (!r) return;
-    if (!r->parts.empty()) {
+    if (!r->parts.empty() || r->chunked) {
         for (kmx_result* p : r->parts) kmx_result_free(p);     // each part returns to its replica's pool
         r->parts.clear();
+        if (r->worker) kmx_result_free(r->worker);
+        r->worker = nullptr;
         r->release();
         delete r;
         return;

@@ -142,3 +142,45 @@ def test_index_freed_before_a_pending_async_result(engine):
     assert res.counts()["n_hits"] == want[1].size
     assert _same(res.host(), want)
     res.close()
+
+
+def test_batches_too_large_for_one_pass_are_streamed_in_chunks(engine, monkeypatch):
+    """kmx_search_batch streams a batch that does not fit the device in one pass chunk by chunk (KMX_HOST_CHUNK forces small
+    chunks here): counts, host views and masks of the whole batch equal the one-pass result; the handle is reusable."""
+    text = synth.ranks(1003, 400_000, 4)
+    ks = [8, 10, 12]
+    q, off = make_queries(text, 4, [3, 6, 8, 9, 10, 12, 13, 20, 22, 24, 31, 36], 400, seed=17)
+    idx = engine.Index(text, 4, ks, keep_host_arena=True)
+    r1 = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS)
+    want, c1 = r1.host(), r1.counts()
+    base1, words1, cnt1, src1 = r1.masks()
+    import ctypes as C
+    st = np.nonzero(want[3] == engine.KIND_STITCH)[0]
+    w1 = np.ctypeslib.as_array(C.cast(words1, C.POINTER(C.c_uint64)), shape=(int((base1[st] + cnt1[st] // 64 + 1).max()),)).copy()
+    monkeypatch.setenv("KMX_HOST_CHUNK", "1000")
+    rc = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS)
+    assert rc.n_parts() == (off.size - 1 + 999) // 1000 and rc.counts() == c1
+    assert _same(rc.host(), want)
+    basen, wordsn, cntn, srcn = rc.masks()
+    wn = np.ctypeslib.as_array(C.cast(wordsn, C.POINTER(C.c_uint64)), shape=(int((basen[st] + cntn[st] // 64 + 1).max()),))
+    assert np.array_equal(cntn[st], cnt1[st]) and np.array_equal(srcn[st], src1[st])
+    for i in st[::7]:
+        nw = int(cnt1[i]) // 64 + 1
+        assert np.array_equal(w1[int(base1[i]):int(base1[i]) + nw], wn[int(basen[i]):int(basen[i]) + nw])
+    with pytest.raises(engine.KmxError):
+        rc.device_ptrs()
+    # the chunked handle serves the next batches too: another chunked one, a small one, an empty one
+    half = (off.size - 1) // 2
+    r2 = idx.search(q[:int(off[half])], off[:half + 1], result=rc)
+    h2 = r2.host()
+    assert np.array_equal(h2[0], want[0][:half + 1]) and np.array_equal(h2[1], want[1][:int(want[0][half])])
+    monkeypatch.setenv("KMX_HOST_CHUNK", "100000000")
+    r3 = idx.search(q[:int(off[50])], off[:51], result=rc)
+    assert np.array_equal(r3.host()[1], want[1][:int(want[0][50])]) and r3.counts()["nq"] == 50
+    r4 = idx.search(np.zeros(0, np.uint8), np.zeros(1, np.uint64), result=rc)
+    assert r4.counts()["nq"] == 0 and r4.host()[0].tolist() == [0]
+    # a plain handle turned into the worker of a chunked batch
+    monkeypatch.setenv("KMX_HOST_CHUNK", "777")
+    r5 = idx.search(q, off, result=r1)
+    assert _same(r5.host(), want) and r5.counts() == c1
+    rc.close(); r5.close(); idx.close()
