@@ -1481,10 +1481,11 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
                             uint32_t flags, kmx_result** out)
 {
     if (!cix || !out) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL argument");
-    if (nq && (!qranks || !qoff)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL query buffers");
+    if (nq && !qoff) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL query offsets");
     if (nq && qoff[0] != 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: qoff[0] must be 0");
     for (uint64_t i = 0; i < nq; ++i)
         if (qoff[i + 1] < qoff[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: qoff must be non-decreasing");
+    if (nq && !qranks && qoff[nq] != 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL query letters");   // (a batch of empty queries has none)
     kmx_index* ix = const_cast<kmx_index*>(cix);
     const size_t W = ix->n_replicas();
     if (W == 1) {

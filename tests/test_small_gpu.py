@@ -116,3 +116,15 @@ def test_batches_the_small_kernel_declines_fall_back(engine, orc):
     st = idx.stats()
     assert st["k_small"]["launches"] == len(cases) - 1 and st["k_lookup"]["launches"] >= 4    # tried (but for the 45), declined, served by the general path
     idx.close()
+
+
+def test_batch_of_nothing_but_empty_queries(engine):
+    """Found by the fuzz soak of round 2: a batch whose queries are all empty has no letters — a NULL letter pointer is fine."""
+    text = synth.ranks(9, 10_000, 4)
+    idx = engine.Index(text, 4, [5])
+    for nq in (1, 3, 300):
+        r = idx.search(np.zeros(0, np.uint8), np.zeros(nq + 1, np.uint64))
+        h = r.host()
+        assert h[0].tolist() == [0] * (nq + 1) and (h[2] == engine.Q_EMPTY_QUERY).all() and r.counts()["n_error"] == nq
+        r.close()
+    idx.close()
