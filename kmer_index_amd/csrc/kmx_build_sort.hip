@@ -3,14 +3,14 @@
 //   hash every k-mer -> (hash, position) pairs -> stable radix sort by hash (positions stay ascending inside a
 //   key, the order push_back yields at :160-167) -> heads of the runs -> distinct keys + offsets -> open-addressing
 //   slots claimed with one 64-bit compare-and-swap each.
-// The sort itself is rocPRIM's device radix sort (vendor library for a plain library step, not on the search
-// path); everything around it is written here.
+// The sort is a least-significant-digit radix sort written here (8-bit digits, per pass: per-tile digit histograms -> one
+// exclusive scan over the digit-major (digit, tile) counts -> stable scatter: round by round inside a tile, wave by wave
+// inside a round, lane order inside a wave through ballot matching), over exactly the bits sigma^k needs.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <cstring>
-
-#include <rocprim/device/device_radix_sort.hpp>
 
 #include "kmx_kernels.h"
 
@@ -79,6 +79,76 @@ __global__ __launch_bounds__(kBlock) void k_sparse_slots(const uint64_t* __restr
     }
 }
 
+// ---- LSD radix sort of (u64 key, u32 value) pairs, stable ----
+constexpr unsigned int kSortItems = 16;                       // elements per thread and tile
+constexpr unsigned int kSortTile = kBlock * kSortItems;       // 4096 per workgroup
+
+__global__ __launch_bounds__(kBlock) void k_rs_hist(const uint64_t* __restrict__ keys, uint64_t n, uint32_t shift,
+                                                    uint32_t* __restrict__ tile_hist, uint32_t n_tiles)
+{
+    __shared__ unsigned int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t base = uint64_t(blockIdx.x) * kSortTile;
+#pragma unroll 4
+    for (unsigned int r = 0; r < kSortItems; ++r) {
+        const uint64_t i = base + uint64_t(r) * kBlock + threadIdx.x;
+        if (i < n) atomicAdd(&h[(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    tile_hist[uint64_t(threadIdx.x) * n_tiles + blockIdx.x] = h[threadIdx.x];     // digit-major: one scan orders (digit, tile)
+}
+
+__global__ __launch_bounds__(kBlock) void k_rs_scatter(const uint64_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in, uint64_t n,
+                                                       uint32_t shift, const uint64_t* __restrict__ tile_off, uint32_t n_tiles,
+                                                       uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out)
+{
+    constexpr unsigned int NW = kBlock / 64;
+    __shared__ unsigned long long goff[256];                   // where this tile's elements of a digit go
+    __shared__ unsigned int run[256];                           // ... of which the earlier rounds have placed this many
+    __shared__ unsigned int wcnt[NW][256];                      // elements of a digit per wave in the current round
+    const unsigned int tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+    goff[tid] = tile_off[uint64_t(tid) * n_tiles + blockIdx.x];
+    run[tid] = 0;
+    const uint64_t base = uint64_t(blockIdx.x) * kSortTile;
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    for (unsigned int r = 0; r < kSortItems; ++r) {
+#pragma unroll
+        for (unsigned int w = 0; w < NW; ++w) wcnt[w][tid] = 0;
+        __syncthreads();
+        const uint64_t i = base + uint64_t(r) * kBlock + tid;
+        const bool valid = i < n;
+        const uint64_t key = valid ? keys_in[i] : 0;
+        const uint32_t val = valid ? vals_in[i] : 0u;
+        const uint32_t dgt = uint32_t(key >> shift) & 255u;
+        // the lanes of this wave that hold the same digit (ballot matching over the 8 digit bits)
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const bool bit = (dgt >> b) & 1u;
+            const uint64_t bal = __ballot(bit);
+            same &= bit ? bal : ~bal;
+        }
+        const uint32_t rank = uint32_t(__popcll(same & below));
+        if (valid && rank == 0) wcnt[wv][dgt] = uint32_t(__popcll(same));
+        __syncthreads();
+        uint32_t pre = 0, tot = 0;
+#pragma unroll
+        for (unsigned int w = 0; w < NW; ++w) {
+            const uint32_t c = wcnt[w][dgt];
+            pre += w < wv ? c : 0u;
+            tot += c;
+        }
+        if (valid) {
+            const unsigned long long dst = goff[dgt] + run[dgt] + pre + rank;
+            keys_out[dst] = key;
+            vals_out[dst] = val;
+        }
+        __syncthreads();                                        // every thread has read run[] and wcnt[]
+        if (valid && rank == 0 && pre == 0) run[dgt] += tot;    // (the first wave that holds the digit)
+    }
+}
+
 struct Temp {
     void* p = nullptr;
     ~Temp() { if (p) (void)hipFree(p); }
@@ -94,13 +164,30 @@ inline unsigned int blocks(uint64_t n) { return (unsigned int)((n + kBlock - 1) 
 static hipError_t sort_pairs(hipStream_t s, const uint8_t* d_text, uint64_t npos, uint32_t k, uint32_t sigma, uint32_t key_bits,
                              uint64_t* keys_a, uint64_t* keys_b, uint32_t* vals, uint32_t* d_positions)
 {
-    hipLaunchKernelGGL(k_sparse_pairs, dim3(blocks(npos)), dim3(kBlock), 0, s, d_text, npos, k, sigma, keys_a, vals);
-    Temp sort_tmp;
-    size_t tmp_bytes = 0;
-    hipError_t e = rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals, d_positions, size_t(npos), 0u, key_bits, s);
-    if (e == hipSuccess) e = sort_tmp.alloc(tmp_bytes);
-    if (e == hipSuccess) e = rocprim::radix_sort_pairs(sort_tmp.p, tmp_bytes, keys_a, keys_b, vals, d_positions, size_t(npos), 0u, key_bits, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);                      // sort_tmp is released on return
+    const uint32_t passes = std::max<uint32_t>(1, (key_bits + 7) / 8);
+    const uint32_t n_tiles = uint32_t((npos + kSortTile - 1) / kSortTile);
+    Temp hist, offs, bsum;
+    hipError_t e = hist.alloc(size_t(256) * n_tiles * 4);
+    if (e == hipSuccess) e = offs.alloc((size_t(256) * n_tiles + 1) * 8);
+    if (e == hipSuccess) e = bsum.alloc((scan_blocks(uint64_t(256) * n_tiles) + 2) * 8);
+    if (e != hipSuccess) return e;
+    unsigned long long* d_total = reinterpret_cast<unsigned long long*>(bsum.as<uint64_t>() + scan_blocks(uint64_t(256) * n_tiles));
+    // the passes ping-pong between (keys_a, vals) and (keys_b, d_positions); the pairs start where an odd number of hops ends in b
+    uint64_t* kin = (passes & 1u) ? keys_a : keys_b;
+    uint32_t* vin = (passes & 1u) ? vals : d_positions;
+    uint64_t* kout = (passes & 1u) ? keys_b : keys_a;
+    uint32_t* vout = (passes & 1u) ? d_positions : vals;
+    hipLaunchKernelGGL(k_sparse_pairs, dim3(blocks(npos)), dim3(kBlock), 0, s, d_text, npos, k, sigma, kin, vin);
+    for (uint32_t p = 0; p < passes; ++p) {
+        const uint32_t shift = 8 * p;
+        hipLaunchKernelGGL(k_rs_hist, dim3(n_tiles), dim3(kBlock), 0, s, kin, npos, shift, hist.as<uint32_t>(), n_tiles);
+        launch_scan(s, hist.as<uint32_t>(), uint64_t(256) * n_tiles, bsum.as<uint64_t>(), offs.as<uint64_t>(), d_total);
+        hipLaunchKernelGGL(k_rs_scatter, dim3(n_tiles), dim3(kBlock), 0, s, kin, vin, npos, shift, offs.as<uint64_t>(), n_tiles, kout, vout);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);                      // the temporaries are released on return
     return e;
 }
 
