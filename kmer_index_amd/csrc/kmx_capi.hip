@@ -223,7 +223,8 @@ struct kmx_result {
     uint64_t* v_hit_off = nullptr; uint32_t* v_positions = nullptr; uint8_t* v_status = nullptr; uint8_t* v_kinds = nullptr;   // the current host view
     const uint64_t* m_base = nullptr; const uint64_t* m_words = nullptr; const uint32_t* m_ccnt = nullptr; const uint64_t* m_csrc = nullptr;   // ... and mask view
     // the latency path (k_small): queries in, complete result out through one page-locked block the kernel reads and writes
-    HostBuf mailbox;
+    HostBuf mailbox, small_in;
+    DevBuf small_xchg;                     // the totals the workgroups of a multi-workgroup k_small launch exchange
     bool small_valid = false;              // the result of the last search lives in the mailbox only (no device buffers were written)
     bool host_valid = false, host_masks_valid = false;
     bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
@@ -248,7 +249,7 @@ struct kmx_result {
     {
         size_t b = 0;
         for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
-                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
+                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff, &small_xchg})
             b += d->cap;
         return b;
     }
@@ -256,9 +257,9 @@ struct kmx_result {
     void release()
     {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
-                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff})
+                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff, &small_xchg})
             b->release();
-        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox})
+        for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox, &small_in})
             b->release();
         if (h_ctr) (void)hipHostFree(h_ctr);
         h_ctr = nullptr;
@@ -1338,44 +1339,72 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
     if (!r->own_stream) HIP_TRY(hipStreamCreateWithFlags(&r->own_stream, hipStreamNonBlocking));
     const uint64_t nq = q1 - q0;
     const uint64_t l0 = nq ? qoff[q0] : 0, n_letters = nq ? qoff[q1] - l0 : 0;
-    // A handful of queries (kmer_index::search(query) is a batch of one): one launch that reads the queries from and
-    // writes the whole result to a page-locked block — no copies, no counter read-back, one wait.
+    // A handful of queries (kmer_index::search(query) is a batch of one; up to 8192 queries in 32 workgroups): one launch that
+    // reads the queries from and writes the whole result to page-locked blocks — no copies, no counter read-back, one wait.
     static const bool no_small = getenv("KMX_NO_SMALL") != nullptr;
-    bool small = nq && nq <= KMX_SMALL_NQ && (nq + 1) * 8 + n_letters <= KMX_SMALL_IN_BYTES && !(flags & KMX_SEARCH_COUNT_ONLY) && !no_small;
-    if (small && nq > KMX_SMALL_WSLOW) {
-        // queries whose length is none of the index's ks are cross-referenced or sub-k ones: more of them than the kernel
+    const uint32_t n_sb = uint32_t((nq + KMX_SMALL_NQ - 1) / KMX_SMALL_NQ);
+    bool small = nq && n_sb <= KMX_SMALL_BLOCKS && !(flags & KMX_SEARCH_COUNT_ONLY) && !no_small;
+    KmxSmallArgs sargs{};
+    for (uint32_t b = 0; small && b < n_sb; ++b) {
+        const uint64_t b0 = q0 + uint64_t(b) * KMX_SMALL_NQ, b1 = std::min(q1, b0 + KMX_SMALL_NQ);
+        const uint64_t letters = qoff[b1] - qoff[b0];
+        small = (b1 - b0 + 1) * 8 + letters <= KMX_SMALL_IN_BYTES;
+        sargs.nq[b] = uint16_t(b1 - b0);
+        sargs.n_letters[b] = uint16_t(letters);
+        // queries whose length is none of the index's ks are cross-referenced or sub-k ones: more of them than a workgroup
         // takes would only cost a declined launch
         uint32_t maybe_slow = 0;
-        for (uint64_t i = 0; i < nq; ++i) {
-            const uint64_t m = qoff[q0 + i + 1] - qoff[q0 + i];
-            maybe_slow += std::find(ix->ks.begin(), ix->ks.end(), uint32_t(m)) == ix->ks.end();
-        }
-        small = maybe_slow <= KMX_SMALL_WSLOW + KMX_SMALL_BSLOW;
+        for (uint64_t i = b0; small && b1 - b0 > KMX_SMALL_WSLOW && i < b1; ++i)
+            maybe_slow += std::find(ix->ks.begin(), ix->ks.end(), uint32_t(qoff[i + 1] - qoff[i])) == ix->ks.end();
+        small = small && maybe_slow <= KMX_SMALL_WSLOW + KMX_SMALL_BSLOW;
     }
-    if (small && r->mailbox.ensure_pinned(KMX_SMALL_BYTES)) {
-        unsigned char* mb = r->mailbox.as<unsigned char>();
-        uint64_t* in_off = reinterpret_cast<uint64_t*>(mb);
-        for (uint64_t i = 0; i <= nq; ++i) in_off[i] = qoff[q0 + i] - l0;
-        if (n_letters) memcpy(mb + (nq + 1) * 8, qranks + l0, n_letters);
-        KmxSmallHeader* hdr = reinterpret_cast<KmxSmallHeader*>(mb + KMX_SMALL_OFF_HEADER);
-        hdr->fallback = 2;                                        // (overwritten by the kernel)
+    // the mailbox is laid out for 1, 4 or 32 workgroups (7 MB page-locked for the largest: allocated once per result handle)
+    const KmxSmallLayout L = kmx_small_layout(n_sb <= 1 ? 1u : n_sb <= 4 ? 4u : uint32_t(KMX_SMALL_BLOCKS));
+    if (small && n_sb > 1 && r->small_xchg.ensure(KMX_SMALL_BLOCKS * 8) != hipSuccess) { (void)hipGetLastError(); small = false; }
+    if (small && r->mailbox.ensure_pinned(L.bytes)) {
+        unsigned char* mb0 = r->mailbox.as<unsigned char>();
+        for (uint32_t b = 0; b < n_sb; ++b) {
+            unsigned char* in = mb0 + size_t(b) * KMX_SMALL_IN_BYTES;
+            const uint64_t b0 = q0 + uint64_t(b) * KMX_SMALL_NQ, lb = qoff[b0];
+            uint64_t* in_off = reinterpret_cast<uint64_t*>(in);
+            for (uint32_t i = 0; i <= sargs.nq[b]; ++i) in_off[i] = qoff[b0 + i] - lb;
+            if (sargs.n_letters[b]) memcpy(in + (size_t(sargs.nq[b]) + 1) * 8, qranks + lb, sargs.n_letters[b]);
+            reinterpret_cast<KmxSmallHeader*>(mb0 + L.off_header)[b].fallback = 2;          // (overwritten by the kernel)
+        }
         (void)hipGetLastError();
-        timed(ix, K_SMALL, r->own_stream, [&] { kmx::launch_small(r->own_stream, ix->d_index, ix->d_arena, mb, uint32_t(nq), uint32_t(n_letters), flags); });
+        unsigned long long* xchg = n_sb > 1 ? r->small_xchg.as<unsigned long long>() : nullptr;
+        if (xchg) HIP_TRY(hipMemsetAsync(xchg, 0, KMX_SMALL_BLOCKS * 8, r->own_stream));
+        timed(ix, K_SMALL, r->own_stream, [&] { kmx::launch_small(r->own_stream, ix->d_index, ix->d_arena, mb0, L, n_sb, sargs, uint32_t(nq), xchg, flags); });
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(r->own_stream));
-        if (hdr->fallback == 0) {
+        const KmxSmallHeader* hdrs = reinterpret_cast<const KmxSmallHeader*>(mb0 + L.off_header);
+        bool all_ok = true;
+        for (uint32_t b = 0; b < n_sb; ++b) all_ok = all_ok && hdrs[b].fallback == 0;
+        if (all_ok) {
             r->index = ix; r->device = ix->device; r->stream = r->own_stream; r->flags = flags & ~KMX_SEARCH_ASYNC;
-            r->nq = nq; r->n_hits = hdr->n_hits; r->n_mask_words = hdr->n_mask_words;
-            r->n_stitch = hdr->n_stitch; r->n_prefix = hdr->n_prefix; r->n_error = hdr->n_error; r->n_none = hdr->n_none;
+            r->nq = nq;
+            r->n_hits = r->n_mask_words = r->n_stitch = r->n_prefix = r->n_error = r->n_none = 0;
+            for (uint32_t b = 0; b < n_sb; ++b) {
+                r->n_hits += hdrs[b].n_hits; r->n_mask_words += hdrs[b].n_mask_words;
+                r->n_stitch += hdrs[b].n_stitch; r->n_prefix += hdrs[b].n_prefix; r->n_error += hdrs[b].n_error; r->n_none += hdrs[b].n_none;
+            }
             r->n_exact = nq - r->n_stitch - r->n_prefix - r->n_error - r->n_none;
-            r->v_hit_off = reinterpret_cast<uint64_t*>(mb + KMX_SMALL_OFF_HITOFF);
-            r->v_positions = reinterpret_cast<uint32_t*>(mb + KMX_SMALL_OFF_POS);
-            r->v_status = mb + KMX_SMALL_OFF_STATUS;
-            r->v_kinds = mb + KMX_SMALL_OFF_KINDS;
-            r->m_base = reinterpret_cast<const uint64_t*>(mb + KMX_SMALL_OFF_MBASE);
-            r->m_words = reinterpret_cast<const uint64_t*>(mb + KMX_SMALL_OFF_WORDS);
-            r->m_ccnt = reinterpret_cast<const uint32_t*>(mb + KMX_SMALL_OFF_CCNT);
-            r->m_csrc = reinterpret_cast<const uint64_t*>(mb + KMX_SMALL_OFF_CSRC);
+            // the workgroups wrote into ONE set of arrays: the views are the mailbox
+            r->v_hit_off = reinterpret_cast<uint64_t*>(mb0 + L.off_hitoff);
+            r->v_positions = reinterpret_cast<uint32_t*>(mb0 + L.off_pos);
+            r->v_status = mb0 + L.off_status;
+            r->v_kinds = mb0 + L.off_kinds;
+            r->m_base = reinterpret_cast<const uint64_t*>(mb0 + L.off_mbase);
+            r->m_words = reinterpret_cast<const uint64_t*>(mb0 + L.off_words);
+            r->m_ccnt = reinterpret_cast<const uint32_t*>(mb0 + L.off_ccnt);
+            r->m_csrc = reinterpret_cast<const uint64_t*>(mb0 + L.off_csrc);
+            // the queries themselves, should device views be asked for later (kmx_result_view_device runs the device form then)
+            if (!r->small_in.ensure_pageable((nq + 1) * 8 + n_letters + 16)) return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_search_batch: host allocation failed");
+            {
+                uint64_t* io = r->small_in.as<uint64_t>();
+                for (uint64_t i = 0; i <= nq; ++i) io[i] = qoff[q0 + i] - l0;
+                if (n_letters) memcpy(r->small_in.as<unsigned char>() + (nq + 1) * 8, qranks + l0, n_letters);
+            }
             r->host_valid = r->host_masks_valid = true;
             r->small_valid = true;
             r->quiesced = true;
@@ -1583,7 +1612,7 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
         // mailbox) through the device form now
         kmx_result* rr = const_cast<kmx_result*>(r);
         kmx_index* ix = const_cast<kmx_index*>(rr->index);
-        const unsigned char* mb = rr->mailbox.as<unsigned char>();
+        const unsigned char* mb = rr->small_in.as<unsigned char>();
         const uint64_t nq = rr->nq, n_letters = reinterpret_cast<const uint64_t*>(mb)[nq];
         HIP_TRY(hipSetDevice(rr->device));
         HIP_TRY(rr->in_qranks.ensure(std::max<uint64_t>(n_letters, 1) + 16));

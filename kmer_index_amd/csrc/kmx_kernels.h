@@ -29,7 +29,9 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
 // the whole search of a small batch in one launch; `mailbox` is page-locked host memory (layout: kmx_types.h)
-void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags);
+// n_blocks workgroups; xchg: n_blocks zeroed u64 words of device memory (the workgroups' totals), may be NULL for one workgroup
+void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, const KmxSmallLayout& layout, uint32_t n_blocks,
+                  const KmxSmallArgs& args, uint32_t nq_total, unsigned long long* xchg, uint32_t flags);
 uint64_t scan_blocks(uint64_t n);
 void launch_build_dir(hipStream_t s, const uint64_t* d_ukeys, uint64_t n_ukeys, uint32_t shift, uint32_t n_dir, uint32_t* d_dir);
 // cells of a dense element (KmxElemDev::cnt8): d_region = the element's contiguous copy, d_cells = cell 0

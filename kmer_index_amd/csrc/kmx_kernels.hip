@@ -1372,9 +1372,16 @@ __device__ __forceinline__ uint32_t stitch_n_extra(const KmxIndexDev* __restrict
     return uint32_t(m / k) - 1u + ((m % k) ? 1u : 0u);
 }
 
+#define KMX_SMALL_XFLAG (1ull << 63)          // an exchange word that has been published: FLAG | hits << 32 | mask words
+#define KMX_SMALL_SPIN_LIMIT (1u << 20)       // polls of one exchange word before the workgroup gives up (~0.1 s)
 __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
-                                                     unsigned char* __restrict__ mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags)
+                                                     unsigned char* __restrict__ mailbox, KmxSmallLayout L, KmxSmallArgs args,
+                                                     uint32_t nq_total, unsigned long long* __restrict__ xchg, uint32_t flags)
 {
+    // a workgroup = up to 256 consecutive queries: queries [blk * 256, ...) of the batch
+    const uint32_t blk = blockIdx.x, qb = blk * KMX_SMALL_NQ;
+    const uint32_t nq = args.nq[blk], n_letters = args.n_letters[blk];
+    const unsigned char* __restrict__ in_area = mailbox + size_t(blk) * KMX_SMALL_IN_BYTES;
     constexpr uint32_t NW = KMX_BLOCK / KMX_WAVE;
     static_assert(NW * KMX_SMALL_WCAP == KMX_SMALL_SORT, "the waves share the sort buffer of the workgroup");
     __shared__ __attribute__((aligned(16))) unsigned char s_in[KMX_SMALL_IN_BYTES + 16];
@@ -1387,7 +1394,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
     __shared__ uint16_t s_wslow[KMX_SMALL_WSLOW], s_bslow[KMX_SMALL_BSLOW];
     __shared__ uint32_t s_n_wslow, s_n_bslow, s_n_words, s_bad, s_valid, s_n_stitch, s_n_prefix, s_n_error, s_n_none;
     const uint32_t tid = threadIdx.x, lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
-    KmxSmallHeader* __restrict__ hdr = reinterpret_cast<KmxSmallHeader*>(mailbox + KMX_SMALL_OFF_HEADER);
+    KmxSmallHeader* __restrict__ hdr = reinterpret_cast<KmxSmallHeader*>(mailbox + L.off_header) + blk;
+    // a workgroup that gives up still publishes its exchange word: the workgroups behind it must not wait for ever
+    auto decline = [&] {
+        if (threadIdx.x == 0) {
+            hdr->fallback = 1;
+            if (xchg) __hip_atomic_store((KMX_GLOBAL unsigned long long*)xchg + blk, KMX_SMALL_XFLAG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
     auto wsync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1397,7 +1411,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
     // 0. the queries out of host memory (one PCIe round trip for the lot), the element descriptors out of HBM
     {
         const uint32_t in_bytes = (nq + 1) * 8 + n_letters;
-        const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(mailbox);
+        const uint4* __restrict__ src4 = reinterpret_cast<const uint4*>(in_area);
         uint4* dst4 = reinterpret_cast<uint4*>(s_in);
         for (uint32_t i = tid; i < (in_bytes + 15) / 16; i += KMX_BLOCK) dst4[i] = src4[i];
         const uint32_t n_words = ix->n_ks * uint32_t(sizeof(KmxElemDev) / 8);
@@ -1446,7 +1460,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
     }
     __syncthreads();
     if (s_bad || s_n_wslow > KMX_SMALL_WSLOW || s_n_bslow > KMX_SMALL_BSLOW) {
-        if (tid == 0) hdr->fallback = 1;
+        decline();
         return;
     }
     // fewer small slow queries than waves: the whole workgroup takes them too, one after the other (a wave per query would
@@ -1502,7 +1516,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
         uint64_t total = 0;
         const uint64_t ex = block_exclusive_scan_u64(tid < nq ? s_cnt[tid] : 0u, &total);
         if (total > KMX_SMALL_POS) {
-            if (tid == 0) hdr->fallback = 1;
+            decline();
             return;
         }
         s_off[tid] = uint32_t(ex);
@@ -1511,48 +1525,121 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
     __syncthreads();
     const uint32_t total = s_off[KMX_SMALL_NQ];
 
+    // 3b. where this workgroup's hits and mask words go in the batch's arrays: behind those of the workgroups in front.
+    //     Every workgroup publishes one word (its totals) and reads the words of its predecessors — at most 31, all resident
+    //     (the grid is at most 32 workgroups), polled by one wave with a bounded spin.
+    uint32_t hit_base = 0, word_base = 0;
+    if (xchg) {
+        __shared__ uint32_t s_hit_base, s_word_base, s_gave_up;
+        if (wv == 0) {
+            if (lane == 0)
+                __hip_atomic_store((KMX_GLOBAL unsigned long long*)xchg + blk, KMX_SMALL_XFLAG | (uint64_t(total) << 32) | s_n_words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long wd = KMX_SMALL_XFLAG;
+            bool gave_up = false;
+            if (lane < blk) {
+                unsigned int spins = 0;
+                for (;;) {
+                    wd = __hip_atomic_load((KMX_GLOBAL unsigned long long*)xchg + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (wd & KMX_SMALL_XFLAG) break;
+                    if (++spins > KMX_SMALL_SPIN_LIMIT) { gave_up = true; wd = KMX_SMALL_XFLAG; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            uint64_t hsum = (wd >> 32) & 0x7FFFFFFFu, wsum = wd & 0xFFFFFFFFu;
+            for (int off = 32; off > 0; off >>= 1) { hsum += __shfl_xor(hsum, off); wsum += __shfl_xor(wsum, off); }
+            if (lane == 0) { s_hit_base = uint32_t(hsum); s_word_base = uint32_t(wsum); s_gave_up = __any(gave_up) ? 1u : 0u; }
+        }
+        __syncthreads();
+        if (s_gave_up) {
+            if (tid == 0) hdr->fallback = 1;                            // (its own word is out already)
+            return;
+        }
+        hit_base = s_hit_base; word_base = s_word_base;
+    }
+
     // 4. the per-query arrays and the mask words, straight into the host block
     {
-        uint64_t* __restrict__ o_off = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_HITOFF);
-        uint64_t* __restrict__ o_csrc = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_CSRC);
-        uint64_t* __restrict__ o_mbase = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_MBASE);
-        uint32_t* __restrict__ o_ccnt = reinterpret_cast<uint32_t*>(mailbox + KMX_SMALL_OFF_CCNT);
-        uint64_t* __restrict__ o_words = reinterpret_cast<uint64_t*>(mailbox + KMX_SMALL_OFF_WORDS);
+        uint64_t* __restrict__ o_off = reinterpret_cast<uint64_t*>(mailbox + L.off_hitoff) + qb;
+        uint64_t* __restrict__ o_csrc = reinterpret_cast<uint64_t*>(mailbox + L.off_csrc) + qb;
+        uint64_t* __restrict__ o_mbase = reinterpret_cast<uint64_t*>(mailbox + L.off_mbase) + qb;
+        uint32_t* __restrict__ o_ccnt = reinterpret_cast<uint32_t*>(mailbox + L.off_ccnt) + qb;
+        uint64_t* __restrict__ o_words = reinterpret_cast<uint64_t*>(mailbox + L.off_words) + word_base;
         if (tid < nq) {
-            o_off[tid] = s_off[tid];
+            o_off[tid] = uint64_t(hit_base) + s_off[tid];
             o_csrc[tid] = s_src[tid] & ~SRC_FLAGS;
-            o_mbase[tid] = s_aux[tid];
+            o_mbase[tid] = s_aux[tid] + word_base;
             o_ccnt[tid] = s_c0[tid];
-            mailbox[KMX_SMALL_OFF_STATUS + tid] = s_status[tid];
-            mailbox[KMX_SMALL_OFF_KINDS + tid] = s_kind[tid];
+            mailbox[L.off_status + qb + tid] = s_status[tid];
+            mailbox[L.off_kinds + qb + tid] = s_kind[tid];
         }
-        if (tid == 0) o_off[nq] = total;
+        if (tid == 0 && qb + nq == nq_total) o_off[nq] = uint64_t(hit_base) + total;     // (the last workgroup)
         for (uint32_t w = tid; w < s_n_words; w += KMX_BLOCK) o_words[w] = s_words[w];
     }
-    uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(mailbox + KMX_SMALL_OFF_POS);
+    uint32_t* __restrict__ out = reinterpret_cast<uint32_t*>(mailbox + L.off_pos) + hit_base;
 
     // 5a. plain copies, slot-centric: every output slot finds its query (the last one whose offset is <= the slot) and
     //     copies its element; the slots of slow queries are left to 5b
-    for (uint32_t s = tid; s < total; s += KMX_BLOCK) {
-        uint32_t lo = 0, hi = nq;                                       // last q in [0, nq) with s_off[q] <= s
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= s) lo = mid; else hi = mid; }
-        const uint32_t q = lo, idx = s - s_off[q];
+    //     A thread takes 16 CONSECUTIVE slots of a 4096-slot pass: one search for the first, then it walks the queries;
+    //     its 16 loads are independent (all in flight together); the pass is staged in LDS and leaves for the host coalesced.
+    //     (A handful of hits — at most four slots per thread: every slot finds its own query, nothing is staged.)
+    auto slot_value = [&](uint32_t q, uint32_t idx) -> uint32_t {
         const uint8_t kind = s_kind[q];
-        if (kind == KMX_KIND_EXACT) {
-            out[s] = arena[s_src[q] + idx];
-        } else if (kind == KMX_KIND_PREFIX) {
-            // the slice of every k-mer with this prefix, then the last-kmer offsets (kmer_index.hpp:138-146): bit j of aux <-> n - j
-            const uint64_t tmask = s_aux[q];
-            const uint32_t len = s_cnt[q] - uint32_t(__popcll(tmask));
-            if (idx < len) {
-                if (s_c0[q] <= 1 || len <= 1) out[s] = arena[(s_src[q] & ~SRC_FLAGS) + idx];     // one run: already ascending
-            } else {
-                uint32_t t = idx - len;                                 // t-th smallest position = t-th highest bit
-                uint64_t mm = tmask;
-                int bit = 63 - __clzll(mm);
-                while (t--) { mm &= ~(uint64_t(1) << bit); bit = 63 - __clzll(mm); }
-                out[s] = uint32_t(ix->n - uint64_t(bit));
+        if (kind == KMX_KIND_EXACT) return arena[s_src[q] + idx];
+        if (kind != KMX_KIND_PREFIX) return 0xFFFFFFFFu;                // (never a position: "nothing to store" — a slow query's slot)
+        // the slice of every k-mer with this prefix, then the last-kmer offsets (kmer_index.hpp:138-146): bit j of aux <-> n - j
+        const uint64_t tmask = s_aux[q];
+        const uint32_t len = s_cnt[q] - uint32_t(__popcll(tmask));
+        if (idx < len) return (s_c0[q] <= 1 || len <= 1) ? arena[(s_src[q] & ~SRC_FLAGS) + idx] : 0xFFFFFFFFu;     // one run: already ascending
+        uint32_t t = idx - len;                                         // t-th smallest position = t-th highest bit
+        uint64_t mm = tmask;
+        int bit = 63 - __clzll(mm);
+        while (t--) { mm &= ~(uint64_t(1) << bit); bit = 63 - __clzll(mm); }
+        return uint32_t(ix->n - uint64_t(bit));
+    };
+    if (total <= 4 * KMX_BLOCK) {
+        uint32_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t s = tid + uint32_t(u) * KMX_BLOCK;
+            v[u] = 0xFFFFFFFFu;
+            if (s < total) {
+                uint32_t lo = 0, hi = nq;                               // last q in [0, nq) with s_off[q] <= s
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= s) lo = mid; else hi = mid; }
+                v[u] = slot_value(lo, s - s_off[lo]);
             }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != 0xFFFFFFFFu) out[tid + uint32_t(u) * KMX_BLOCK] = v[u];
+    } else {
+        constexpr uint32_t PASS = KMX_SMALL_SORT, PER = PASS / KMX_BLOCK;
+        for (uint32_t p0 = 0; p0 < total; p0 += PASS) {
+            const uint32_t s_first = p0 + tid * PER;
+            uint32_t q = 0;
+            if (s_first < total) {
+                uint32_t lo = 0, hi = nq;                               // last q in [0, nq) with s_off[q] <= s_first
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (s_off[mid] <= s_first) lo = mid; else hi = mid; }
+                q = lo;
+            }
+            uint32_t v[PER];
+#pragma unroll
+            for (uint32_t u = 0; u < PER; ++u) {
+                const uint32_t s = s_first + u;
+                v[u] = 0xFFFFFFFFu;                                     // (never a position: "nothing to store")
+                if (s < total) {
+                    while (q + 1 < nq && s_off[q + 1] <= s) ++q;        // the owner of slot s (queries without hits are stepped over)
+                    v[u] = slot_value(q, s - s_off[q]);
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < PER; ++u) s_sort[tid * PER + u] = v[u];
+            __syncthreads();
+            const uint32_t n_here = min(PASS, total - p0);
+            for (uint32_t i = tid; i < n_here; i += KMX_BLOCK) {
+                const uint32_t x = s_sort[i];
+                if (x != 0xFFFFFFFFu) out[p0 + i] = x;
+            }
+            __syncthreads();
         }
     }
     // 5b. the slow ones.  STITCH: decode the mask words — the survivor of candidate c lands at the number of set bits before
@@ -1594,9 +1681,10 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_small(const KmxIndexDev* __restri
     }
 }
 
-void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, uint32_t nq, uint32_t n_letters, uint32_t flags)
+void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, const KmxSmallLayout& layout, uint32_t n_blocks,
+                  const KmxSmallArgs& args, uint32_t nq_total, unsigned long long* xchg, uint32_t flags)
 {
-    hipLaunchKernelGGL(k_small, dim3(1), dim3(KMX_BLOCK), 0, s, ix, arena, mailbox, nq, n_letters, flags);
+    hipLaunchKernelGGL(k_small, dim3(n_blocks), dim3(KMX_BLOCK), 0, s, ix, arena, mailbox, layout, args, nq_total, xchg, flags);
 }
 
 __global__ __launch_bounds__(KMX_BLOCK) void k_scan_reduce(const uint32_t* __restrict__ in, uint64_t n,

@@ -98,10 +98,17 @@ struct KmxIndexDev {
 // 128 KB of LDS, k_prefix_sort_block); beyond that the global merge passes.
 #define KMX_PSORT_BLOCK_CAP 32768
 
-// k_small — the latency path of a handful of queries (kmer_index::search(query) is a batch of one): ONE kernel, one
-// workgroup, reads the queries from and writes the complete result to a page-locked host block ("mailbox").
-#define KMX_SMALL_NQ 256          // queries per batch
-#define KMX_SMALL_IN_BYTES 8192   // (nq + 1) offsets + letters, staged in LDS
+// k_small — the latency path of small batches (kmer_index::search(query) is a batch of one): ONE launch of up to
+// KMX_SMALL_BLOCKS workgroups, 256 queries each, that read the queries from and write the complete result to ONE page-locked
+// host block ("mailbox"): per workgroup an input area, then the result arrays of the whole batch, which the workgroups fill
+// at offsets they agree on among themselves (hit and mask-word totals exchanged through device memory).
+#define KMX_SMALL_NQ 256          // queries per workgroup
+#define KMX_SMALL_BLOCKS 32       // workgroups per launch: batches up to 8192 queries take the latency path
+struct KmxSmallArgs {             // per workgroup: its number of queries and of letters (by value in the kernel arguments)
+    uint16_t nq[KMX_SMALL_BLOCKS];
+    uint16_t n_letters[KMX_SMALL_BLOCKS];
+};
+#define KMX_SMALL_IN_BYTES 8192   // per workgroup: (nq + 1) offsets + letters, staged in LDS
 // "slow" queries — cross-referenced ones (STITCH) and sub-k ones whose slice has several runs (PREFIX, wants sorting):
 // up to KMX_SMALL_WSLOW of them with at most KMX_SMALL_WCAP candidates / positions are taken by the workgroup's four waves in
 // parallel, up to KMX_SMALL_BSLOW bigger ones (at most KMX_SMALL_SORT) by the whole workgroup one after the other
@@ -109,26 +116,39 @@ struct KmxIndexDev {
 #define KMX_SMALL_WSLOW 32
 #define KMX_SMALL_SORT 4096
 #define KMX_SMALL_BSLOW 8
-#define KMX_SMALL_WORDS (KMX_SMALL_WSLOW * (KMX_SMALL_WCAP / 64 + 1) + KMX_SMALL_BSLOW * (KMX_SMALL_SORT / 64 + 1))
-#define KMX_SMALL_POS 49152       // hit positions per batch
-struct KmxSmallHeader {
-    uint32_t fallback;            // 1: the batch is not for this kernel (too many hits / slow queries): nothing else is valid
+#define KMX_SMALL_WORDS (KMX_SMALL_WSLOW * (KMX_SMALL_WCAP / 64 + 1) + KMX_SMALL_BSLOW * (KMX_SMALL_SORT / 64 + 1))   // mask words per workgroup
+#define KMX_SMALL_POS 49152       // hit positions per workgroup
+struct KmxSmallHeader {           // one per workgroup
+    uint32_t fallback;            // != 0: the batch is not for this kernel (too many hits / slow queries, or an exchange that ran out): nothing else is valid
     uint32_t nq;
     uint64_t n_hits, n_mask_words;
     uint32_t n_stitch, n_prefix, n_error, n_none;
     uint32_t pad[6];
 };
-// layout of the mailbox: [input: qoff, letters][KmxSmallHeader][the arrays below], offsets in bytes
-#define KMX_SMALL_OFF_HEADER KMX_SMALL_IN_BYTES
-#define KMX_SMALL_OFF_HITOFF (KMX_SMALL_OFF_HEADER + 64)
-#define KMX_SMALL_OFF_CSRC (KMX_SMALL_OFF_HITOFF + (KMX_SMALL_NQ + 1) * 8)
-#define KMX_SMALL_OFF_MBASE (KMX_SMALL_OFF_CSRC + KMX_SMALL_NQ * 8)
-#define KMX_SMALL_OFF_CCNT (KMX_SMALL_OFF_MBASE + KMX_SMALL_NQ * 8)
-#define KMX_SMALL_OFF_STATUS (KMX_SMALL_OFF_CCNT + KMX_SMALL_NQ * 4)
-#define KMX_SMALL_OFF_KINDS (KMX_SMALL_OFF_STATUS + KMX_SMALL_NQ)
-#define KMX_SMALL_OFF_WORDS (KMX_SMALL_OFF_KINDS + KMX_SMALL_NQ)
-#define KMX_SMALL_OFF_POS (KMX_SMALL_OFF_WORDS + KMX_SMALL_WORDS * 8)
-#define KMX_SMALL_BYTES (KMX_SMALL_OFF_POS + KMX_SMALL_POS * 4)
+// byte offsets of a mailbox laid out for `blocks` workgroups:
+//   [blocks x input area][blocks x KmxSmallHeader][hit_off (256 blocks + 1) u64][cand_src u64][mask_base u64][cand_count u32]
+//   [status u8][kinds u8][mask words][positions]
+struct KmxSmallLayout {
+    uint32_t blocks, off_header, off_hitoff, off_csrc, off_mbase, off_ccnt, off_status, off_kinds, off_words, off_pos, bytes, pad;
+};
+static inline KmxSmallLayout kmx_small_layout(uint32_t blocks)
+{
+    KmxSmallLayout L;
+    const uint32_t nq = blocks * KMX_SMALL_NQ;
+    L.blocks = blocks;
+    L.off_header = blocks * KMX_SMALL_IN_BYTES;
+    L.off_hitoff = L.off_header + blocks * 64;
+    L.off_csrc = L.off_hitoff + (nq + 2) * 8;
+    L.off_mbase = L.off_csrc + nq * 8;
+    L.off_ccnt = L.off_mbase + nq * 8;
+    L.off_status = L.off_ccnt + nq * 4;
+    L.off_kinds = L.off_status + nq;
+    L.off_words = L.off_kinds + nq;
+    L.off_pos = L.off_words + blocks * KMX_SMALL_WORDS * 8;
+    L.bytes = L.off_pos + blocks * KMX_SMALL_POS * 4;
+    L.pad = 0;
+    return L;
+}
 
 // Counter block written by the lookup kernel and read back once per batch.
 enum {

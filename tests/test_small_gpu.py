@@ -81,6 +81,32 @@ def test_small_batches_equal_the_general_pipeline(engine, sigma, ks, table):
         assert after["k_small"]["launches"] == before["k_small"]["launches"] + 1 and after["k_lookup"]["launches"] == before["k_lookup"]["launches"]
     for j, i in enumerate(plain):
         assert np.array_equal(h_pos[int(h_off[j]):int(h_off[j + 1])], want[i]) and h_kd[j] == g_kd[i]
+    # several workgroups in one launch (up to 32 x 256 queries): mostly plain lookups, every 17th query a slow one
+    slow = np.nonzero(~np.isin(lens, ks) & (g_st == 0))[0]
+    for total_q in (257, 700, 3000, 8192):
+        pick = np.resize(plain, total_q).copy()
+        pick[::17] = np.resize(slow, pick[::17].size)
+        q, off = pack([qranks[int(qoff[i]):int(qoff[i + 1])] for i in pick])
+        before = idx.stats()
+        r = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS, result=res)
+        after = idx.stats()
+        h_off, h_pos, h_st, h_kd = r.host()
+        blocks_ok = all(sum(want[i].size for i in pick[b:b + 256]) <= 49152 for b in range(0, total_q, 256))
+        if blocks_ok:
+            assert after["k_small"]["launches"] == before["k_small"]["launches"] + 1 and after["k_lookup"]["launches"] == before["k_lookup"]["launches"], total_q
+        assert np.array_equal(h_st, g_st[pick]) and np.array_equal(h_kd, g_kd[pick])
+        assert np.array_equal(np.diff(h_off), np.array([want[i].size for i in pick], np.uint64))
+        assert np.array_equal(h_pos, np.concatenate([want[i] for i in pick]))
+        base, wptr, ccnt, csrc = r.masks()
+        stq = np.nonzero(h_kd == engine.KIND_STITCH)[0]
+        words = _words(wptr, int((base + ccnt // 64 + 1)[stq].max())) if stq.size else None
+        for j in stq[::5]:
+            i = pick[j]
+            nw = int(ccnt[j]) // 64 + 1
+            assert ccnt[j] == g_ccnt[i] and csrc[j] == g_csrc[i]
+            assert np.array_equal(words[int(base[j]):int(base[j]) + nw], g_words[int(g_base[i]):int(g_base[i]) + nw])
+        c = r.counts()
+        assert c["nq"] == total_q and c["n_hits"] == h_pos.size and c["n_stitch"] == stq.size
     # device views of a result that was produced on the latency path: materialised on demand, same contents
     import torch
     q, off = pack([qranks[int(qoff[i]):int(qoff[i + 1])] for i in order[:9]])

@@ -15,8 +15,9 @@ def main():
     n, k = 10_000_000, 10
     text = synth.ranks(1002, n, 4)
     idx = engine.Index(text, 4, [8, k, 12])
-    for nq in (1, 16, 256, 4096, 65536):
-        qr, qoff = synth.mixed_queries(77 + nq, text, nq, [8, 10, 12, 20, 9], 4)
+    for nq, lens in [(n_, [8, 10, 12, 20, 9]) for n_ in (1, 16, 256, 4096, 65536)] + [(n_, [8, 10, 12]) for n_ in (256, 1024, 4096, 8192, 16384)]:
+        qr, qoff = synth.mixed_queries(77 + nq, text, nq, lens, 4)
+        print(f"lengths {lens}:", end=" ")
         for mode in ("fresh", "reused"):
             res = engine.Result()
             idx.search(qr, qoff, result=res).host(copy=False)
