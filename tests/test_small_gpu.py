@@ -132,6 +132,10 @@ def test_batches_the_small_kernel_declines_fall_back(engine, orc):
         "huge candidate list": pack([text[500:508]]),                                   # 4 + 4: ~7800 candidates > 4096
         "many stitch queries": pack([text[s:s + 13] for s in range(1000, 1045)]),       # 45 cross-referenced queries: the host does not even try
         "long prefix slice": pack([text[700:703]]),                                     # m = 3 < 4: 4 runs, ~31000 positions
+        # three workgroups, the second of which finds more hits than it may write: it declines (and still publishes its
+        # totals, so the third does not wait for ever), the whole batch goes to the general pipeline
+        "a workgroup in the middle declines": pack([text[s:s + 6] for s in range(2000, 2256)] + [text[100:104]] * 30 +
+                                                   [text[s:s + 6] for s in range(3000, 3400)]),
     }
     for name, (q, off) in cases.items():
         r = idx.search(q, off)
