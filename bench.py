@@ -61,6 +61,10 @@ def parse_args(argv=None):
     ap.add_argument("--pipeline", type=int, default=2,
                     help="result handles the steps rotate over on ONE stream with KMX_SEARCH_ASYNC: the host enqueues step i+1 while "
                          "step i runs and reads step i's counters when its handle comes round again (1 = every step waits for its own)")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams the result handles of the sharded leg are spread over (handle i on stream i %% streams): with 2, the "
+                         "lookup / scan of step i+1 may run under the tail of step i's fill")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the extra leg that times the same steps with the handles on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
@@ -211,21 +215,24 @@ def worker(args):
     # leg 1 — sharded: hit lists stay in the HBM of the GPU that produced them.  `depth` result handles rotate on one
     # stream with KMX_SEARCH_ASYNC (the host enqueues step i+1 while step i runs).
     # ------------------------------------------------------------------------------------------------------------
-    def run_sharded(index, steps, warmup, collect_stats):
+    sh_streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(max(depth, 2) - 1)]
+
+    def run_sharded(index, steps, warmup, collect_stats, n_streams=1):
+        n_streams = max(1, min(n_streams, depth))
         results = [engine.Result() for _ in range(depth)]
         flags = engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT
         no = [0]
 
         def step():
-            r_ = results[no[0] % depth]
+            h = no[0] % depth
             no[0] += 1
-            index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=flags, stream=main_stream.cuda_stream, result=r_)
+            index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=flags, stream=sh_streams[h % n_streams].cuda_stream, result=results[h])
 
         # setup, like the index build: every result handle allocates its device buffers (grow-only, sized by its first
         # batch) before the W warmup steps, so that neither warmup nor the timed region holds an allocation
-        for r_ in results:
+        for h, r_ in enumerate(results):
             for _ in range(2):
-                index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=main_stream.cuda_stream, result=r_)
+                index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=sh_streams[h % n_streams].cuda_stream, result=r_)
         torch.cuda.synchronize()
         for _ in range(warmup):
             step()
@@ -330,9 +337,24 @@ def worker(args):
 
     # (KMX_BENCH_INIT_PG: a 1-rank process group, so that a 1-GPU box still drives the RCCL code path end to end)
     want_gather = backend is not None and args.gather in ("both", "hits")
-    elapsed, results, stats = run_sharded(idx, args.steps, args.warmup, True)
+    elapsed, results, stats = run_sharded(idx, args.steps, args.warmup, True, args.streams)
     res = results[0]
     counts = res.counts()
+    # the same K steps with the two result handles on TWO streams (step i+1's lookup, scan and fill may overlap step i's):
+    # more queries per second, but concurrent kernels have no meaningful duration of their own, so the roofline line stays
+    # with the one-stream leg above and this one is reported beside it
+    two_streams = None
+    if args.streams == 1 and depth >= 2 and not args.no_two_streams:
+        dt2, res2, _ = run_sharded(idx, args.steps, args.warmup, False, 2)
+        same2 = res2[0].counts()["n_hits"] == counts["n_hits"]
+        t2 = torch.tensor([dt2], dtype=torch.float64, device=comm_dev)
+        if backend is not None:
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dt2 = float(t2.item())
+        two_streams = {"value": round(nq * world * args.steps / dt2 / 1e6, 3), "unit": "M queries/s", "ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                       "same_hit_total": bool(same2), "how": "two result handles on two HIP streams, KMX_SEARCH_ASYNC"}
+        for r_ in res2:
+            r_.close()
     gather_leg = run_gather(idx, args.steps, args.warmup) if want_gather else None
 
     t_el = torch.tensor([elapsed, gather_leg["elapsed"] if gather_leg else 0.0], dtype=torch.float64, device=comm_dev)
@@ -490,10 +512,11 @@ def worker(args):
                                    f"{'(dense)' if info['tables'][0] == engine.TABLE_DENSE else '(open)'}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
                        "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated",
-                       "gather": "hits" if args.gather == "hits" and gather_out else "totals", "pipeline_depth": depth},
+                       "gather": "hits" if args.gather == "hits" and gather_out else "totals", "pipeline_depth": depth, "streams": max(1, min(args.streams, depth))},
             "roofline": roofline,
             "rccl": rccl,
             "gather_hits": gather_out,
+            "two_streams": two_streams,
             "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
             "kernels_avg_ms": kernels_ms,

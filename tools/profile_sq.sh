@@ -9,7 +9,7 @@ out=gpurun_out/sq_${tag}_cfg$cfg
 mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 -L > "$out/counters_available.txt" 2>&1
-BENCH="bench.py --config $cfg --no-cpu-baseline --no-open-compare --steps 4 --warmup 1"
+BENCH="bench.py --config $cfg --no-cpu-baseline --no-open-compare --no-two-streams --steps 4 --warmup 1"
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d "$out/pass1" -o p1 --output-format csv -- python3 $BENCH > "$out/pass1.log" 2>&1
 echo "pass1 rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d "$out/pass2" -o p2 --output-format csv -- python3 $BENCH > "$out/pass2.log" 2>&1

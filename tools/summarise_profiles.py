@@ -80,7 +80,7 @@ def main():
     fill = max((k for k in kernels if k.startswith("kmx::k_fill<")), key=lambda k: kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches"])
     out = {
         "source": f"tools/profile_round.sh {a.tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
-                  "--kernel-trace --stats, each over `python3 bench.py" + (f" --config {a.config}" if a.config != 2 else "") + " --no-cpu-baseline --no-open-compare --steps 8 --warmup 2`, MI355X",
+                  "--kernel-trace --stats, each over `python3 bench.py" + (f" --config {a.config}" if a.config != 2 else "") + " --no-cpu-baseline --no-open-compare --no-two-streams --steps 8 --warmup 2`, MI355X",
         "units": "FETCH_SIZE / WRITE_SIZE are KiB as reported; fetch_bytes_corrected doubles FETCH_SIZE (gfx950 tallies 128-B "
                  "requests at 64 B, MI355X_MICROARCH.md HBM section); calibration in the same run: the largest k_scan_reduce "
                  f"launch reads exactly 4 B x {red_items} items = {4 * red_items} B",
