@@ -1409,6 +1409,7 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
             r->small_valid = true;
             r->quiesced = true;
             r->last_had_stitch = false;
+            r->pool = ix->pool;                                 // (kmx_result_view_device asks it whether the index is still there)
             return KMX_OK;
         }
         // not a batch for the small kernel (too many hits, long candidate lists): the general path below
@@ -1611,6 +1612,11 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
         // the last search ran on the latency path and left nothing in HBM: run the same queries (they are still in the
         // mailbox) through the device form now
         kmx_result* rr = const_cast<kmx_result*>(r);
+        {
+            bool gone = !rr->pool;
+            if (rr->pool) { std::lock_guard<std::mutex> lock(rr->pool->mu); gone = rr->pool->closed; }
+            if (gone) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_view_device: the result was produced on the latency path (host memory only) and its index has been freed");
+        }
         kmx_index* ix = const_cast<kmx_index*>(rr->index);
         const unsigned char* mb = rr->small_in.as<unsigned char>();
         const uint64_t nq = rr->nq, n_letters = reinterpret_cast<const uint64_t*>(mb)[nq];

@@ -158,3 +158,18 @@ def test_batch_of_nothing_but_empty_queries(engine):
         assert h[0].tolist() == [0] * (nq + 1) and (h[2] == engine.Q_EMPTY_QUERY).all() and r.counts()["n_error"] == nq
         r.close()
     idx.close()
+
+
+def test_device_view_of_a_latency_path_result_after_its_index_is_gone(engine):
+    """A result produced by k_small lives in host memory; its device views are materialised on demand from the index — which
+    must still exist: asking after kmx_index_free is an error, not a use of freed memory; the host views stay valid."""
+    text = synth.ranks(9, 50_000, 4)
+    idx = engine.Index(text, 4, [6])
+    q, off = synth.uniform_queries(3, 5, 6, 4)
+    r = idx.search(q, off)
+    want = r.host()
+    idx.close()
+    with pytest.raises(engine.KmxError):
+        r.device_ptrs()
+    assert all(np.array_equal(a, b) for a, b in zip(r.host(), want))
+    r.close()
