@@ -128,3 +128,11 @@ def test_choose_best_k_matches_oracle_and_known_answer(engine, orc):
         lens = rng.integers(1, 2000, int(rng.integers(0, 300)))
         n_k = int(rng.integers(1, 11))
         assert engine.choose_best_k(lens, n_k) == orc.choose_best_k(lens, n_k)
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/kmx.h compiles as C99 with -Wall -Wextra -pedantic: the boundary is a C ABI, not a C++ one."""
+    obj = tmp_path / "hdr.o"
+    res = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", f"-I{os.path.join(ROOT, 'include')}", "-c",
+                          os.path.join(ROOT, "tests", "cpp", "test_header_is_c.c"), "-o", str(obj)], capture_output=True, text=True)
+    assert res.returncode == 0, res.stderr
