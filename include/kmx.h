@@ -168,9 +168,13 @@ uint64_t kmx_fast_pow(uint64_t base, uint8_t exp);
  *      (kmer_index.hpp:505-558) applied to a BATCH of queries, followed by
  *      kmer_index_result::to_vector() (kmer_index_result.hpp:244-260) per query.
  *      qranks: the queries' letters as ranks, concatenated; qoff[nq+1]: start of each
- *      query in qranks (qoff[0] = 0).  Host-buffer form: copies the inputs to the
- *      device, runs the device form on an internal stream, and leaves the result
- *      ready for kmx_result_view. */
+ *      query in qranks (qoff[0] = 0; qranks may be NULL when no query has a letter).  Host-buffer form:
+ *      copies the inputs to the device, runs the device form on a stream owned by the result, and
+ *      leaves the result ready for kmx_result_view.  Small batches (up to 8192 queries that are mostly
+ *      plain lookups; kmer_index::search(query) is a batch of one) take a latency path instead: ONE launch
+ *      that reads the queries from and writes the complete result to page-locked host memory — no copies,
+ *      one wait (about 17-30 us for one query).  Such a result lives in host memory; kmx_result_view_device
+ *      on it runs the device form then (the index must still exist). */
 kmx_status kmx_search_batch(const kmx_index* index, const uint8_t* qranks, const uint64_t* qoff,
                             uint64_t nq, uint32_t flags, kmx_result** out);
 /*      A batch whose descriptors or hit lists do not fit the device in one pass (more than 2^25 queries, or an out-of-memory
