@@ -173,3 +173,41 @@ def test_device_view_of_a_latency_path_result_after_its_index_is_gone(engine):
         r.device_ptrs()
     assert all(np.array_equal(a, b) for a, b in zip(r.host(), want))
     r.close()
+
+
+def test_latency_path_from_concurrent_host_threads(engine):
+    """Several host threads share one index and search one query (or a few) at a time — the reference's call shape, concurrent:
+    every call runs on its result's own stream and mailbox."""
+    import threading
+    text = synth.ranks(77, 300_000, 4)
+    idx = engine.Index(text, 4, [8, 10])
+    q, off = make_queries(text, 4, [6, 8, 10, 13, 18, 20, 25], 80, seed=5)
+    nq = off.size - 1
+    big = idx.search(q, off).host()                                       # general pipeline (560 queries)
+    want = _lists(big[0], big[1])
+    errors = []
+
+    def worker(t):
+        try:
+            rng = np.random.default_rng(t)
+            res = engine.Result()
+            for it in range(120):
+                size = 1 if it % 3 else int(rng.integers(2, 20))
+                b = int(rng.integers(0, nq - size + 1))
+                sq, so = pack([q[int(off[i]):int(off[i + 1])] for i in range(b, b + size)])
+                h = idx.search(sq, so, result=res).host()
+                for j in range(size):
+                    assert np.array_equal(h[1][int(h[0][j]):int(h[0][j + 1])], want[b + j]) and h[2][j] == big[2][b + j]
+            res.close()
+        except Exception as e:  # pragma: no cover
+            errors.append(repr(e))
+
+    idx.stats_enable(True)
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    assert idx.stats()["k_small"]["launches"] >= 8 * 100
+    idx.close()
