@@ -223,6 +223,8 @@ struct kmx_result {
     uint64_t* v_hit_off = nullptr; uint32_t* v_positions = nullptr; uint8_t* v_status = nullptr; uint8_t* v_kinds = nullptr;   // the current host view
     const uint64_t* m_base = nullptr; const uint64_t* m_words = nullptr; const uint32_t* m_ccnt = nullptr; const uint64_t* m_csrc = nullptr;   // ... and mask view
     // the latency path (k_small): queries in, complete result out through one page-locked block the kernel reads and writes
+    uint32_t ctr_phase = 0;                // which of the two device counter blocks the current / last search counts into
+    bool ctr_clean = false;                // the block the NEXT search will use is known to be zero (the last scan published and reset)
     HostBuf mailbox, small_in;
     DevBuf small_xchg;                     // the totals the workgroups of a multi-workgroup k_small launch exchange
     bool small_valid = false;              // the result of the last search lives in the mailbox only (no device buffers were written)
@@ -1149,14 +1151,26 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->stitch_list.ensure(nq * 4));
     HIP_TRY(r->prefix_list.ensure(nq * 4));
     HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(nq), kmx::lookup_blocks(nq)) * 8));
-    HIP_TRY(r->ctr.ensure(KMX_CTR_COUNT * sizeof(unsigned long long)));
+    if (r->ctr.cap < 2 * KMX_CTR_COUNT * sizeof(unsigned long long)) {
+        // two counter blocks per handle, used in turn: the scan of a batch zeroes the block of the next one
+        HIP_TRY(r->ctr.ensure(2 * KMX_CTR_COUNT * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(r->ctr.p, 0, 2 * KMX_CTR_COUNT * sizeof(unsigned long long), s));
+        r->ctr_phase = 0;
+        r->ctr_clean = true;
+    }
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
                      r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
-    auto* ctr = r->ctr.as<unsigned long long>();
+    // this batch's counter block, and the one of the next batch on this handle
+    if (!r->ctr_clean) {                                        // (after a batch whose scan did not reset it: the stream does)
+        HIP_TRY(hipMemsetAsync(r->ctr.p, 0, 2 * KMX_CTR_COUNT * sizeof(unsigned long long), s));
+        r->ctr_clean = true;
+    }
+    r->ctr_phase ^= 1u;
+    auto* ctr = r->ctr.as<unsigned long long>() + r->ctr_phase * KMX_CTR_COUNT;
+    auto* ctr_next = r->ctr.as<unsigned long long>() + (r->ctr_phase ^ 1u) * KMX_CTR_COUNT;
     const KmxIndexDev* dix = ix->d_index;
 
-    HIP_TRY(hipMemsetAsync(ctr, 0, KMX_CTR_COUNT * sizeof(unsigned long long), s));
     timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), flags); });
     // speculative scan: already final when the batch holds no STITCH query
     // The downsweep also records the first query of every output tile (k_partition's job) when the
@@ -1165,10 +1179,15 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     const uint64_t tile = kmx::fill_tile(fv);
     const uint64_t tile_cap = r->tile_q.cap / 4;            // entries available while the scan runs
     // the block sums k_lookup left in bsum are the first level of this scan
+    // (steady state: the scan's last block also hands the counters to the host and zeroes the next batch's block — no
+    //  memset and no copy operation on the stream)
+    bool published = false;
     timed(ix, K_SCAN, s, [&] {
-        kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS, tile,
-                               tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, true);
+        published = kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS, tile,
+                                           tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, true,
+                                           kmx::CounterPub{ctr, ctr_next, r->h_ctr});
     });
+    r->ctr_clean = published;
     // Steady state (tile table and output buffer kept from an earlier batch): k_fill goes out right behind the
     // scan, before the host knows the hit total — it reads the total from device memory and its grid is sized
     // from what the buffers can hold.  Valid whenever the batch holds no STITCH query (their counts come later)
@@ -1181,7 +1200,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
             kmx::launch_fill(s, fv, ix->rec32, dix, ix->d_arena, r->hit_off.as<uint64_t>(), r->tile_q.as<uint32_t>(),
                              ctr + KMX_CTR_TOTAL_HITS, spec_tiles, d, r->out.as<uint32_t>());
         });
-    HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
+    if (!published) HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
     // everything after the read-back lives in search_finish: right away, or (KMX_SEARCH_ASYNC) when the result is next touched
     r->ctx = SearchCtx{ix, qr, qo, s, tile_cap, spec_tiles, spec_fill, true};
     if (flags & KMX_SEARCH_ASYNC) {
@@ -1219,7 +1238,7 @@ static kmx_status search_finish(kmx_result* r)
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
                      r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
-    auto* ctr = r->ctr.as<unsigned long long>();
+    auto* ctr = r->ctr.as<unsigned long long>() + r->ctr_phase * KMX_CTR_COUNT;     // the counter block this search counts into
     const KmxIndexDev* dix = ix->d_index;
     const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
     const uint64_t tile = kmx::fill_tile(fv);

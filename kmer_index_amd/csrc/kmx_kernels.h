@@ -62,8 +62,18 @@ struct FillVariant {
     int e;
     bool nt;
 };
-void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
-                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums);
+// Counter publication folded into the scan (steady state: no memset and no copy operation on the stream): the block that
+// writes the grand total also copies the batch's counter block `cur` to page-locked host memory `host` and zeroes `next`,
+// the block the next batch on this result handle counts into.  All NULL: nothing of the kind.
+struct CounterPub {
+    const unsigned long long* cur = nullptr;
+    unsigned long long* next = nullptr;
+    unsigned long long* host = nullptr;
+};
+// returns true when the publication was done by the scan (the fused-spine path), false when the caller has to copy / reset
+bool launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums,
+                       const CounterPub& pub = CounterPub());
 FillVariant effective_fill_variant(const FillVariant& v, bool rec32);
 uint64_t fill_tile(const FillVariant& v);
 void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q);

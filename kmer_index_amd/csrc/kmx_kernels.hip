@@ -1733,7 +1733,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
                                                          const uint64_t* __restrict__ bsum,
                                                          uint64_t* __restrict__ out, uint64_t tile,
                                                          uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q,
-                                                         unsigned long long* __restrict__ total_out, uint64_t n_fine)
+                                                         unsigned long long* __restrict__ total_out, uint64_t n_fine,
+                                                         CounterPub pub)
 {
     static_assert(KMX_SCAN_TILE % (KMX_BLOCK * KMX_LOOKUP_ITEMS) == 0, "a scan tile is a whole number of lookup blocks");
     // The block's 4096 items as KMX_SCAN_ROWS rows of 1024: in row r thread t owns items r*1024 + 4t .. 4t+3 —
@@ -1789,6 +1790,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
             if constexpr (SPINE == 2) { for (uint64_t i = mine; i < n_fine; ++i) own += bsum[i]; }
             else own = bsum[blockIdx.x];
             *total_out = row_base + own;
+            if (pub.host) {
+                // the batch's counters (k_lookup's, complete since the previous kernel, and the total just written) go to the
+                // host from here, and the counter block of the NEXT batch on this handle starts from zero
+#pragma unroll
+                for (int c = 0; c < KMX_CTR_COUNT; ++c) {
+                    pub.host[c] = c == KMX_CTR_TOTAL_HITS ? row_base + own : pub.cur[c];
+                    pub.next[c] = 0;
+                }
+            }
         }
     } else {
         row_base = bsum[blockIdx.x];
@@ -2346,37 +2356,39 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, 
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
         hipLaunchKernelGGL((k_scan_down<false, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                           (uint32_t*)nullptr, total_out, uint64_t(0));
+                           (uint32_t*)nullptr, total_out, uint64_t(0), CounterPub());
         return;
     }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
     hipLaunchKernelGGL((k_scan_down<false, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                       (uint32_t*)nullptr, total_out, uint64_t(0));
+                       (uint32_t*)nullptr, total_out, uint64_t(0), CounterPub());
 }
 
 // scan + first-query-of-every-tile in one downsweep; tile_q must hold n_tiles_cap + 1 entries (nullptr: plain scan).
 // lookup_sums: bsum already holds k_lookup's per-block sums of `in` (lookup_blocks(n) of them) — no reduce launch.
-void launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
-                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums)
+bool launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums,
+                       const CounterPub& pub)
 {
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
     if (lookup_sums && nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
         const uint64_t n_fine = lookup_blocks(n);
         if (tile_q)
-            hipLaunchKernelGGL((k_scan_down<true, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, n_fine);
+            hipLaunchKernelGGL((k_scan_down<true, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, n_fine, pub);
         else
             hipLaunchKernelGGL((k_scan_down<false, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                               (uint32_t*)nullptr, total_out, n_fine);
-        return;
+                               (uint32_t*)nullptr, total_out, n_fine, pub);
+        return pub.host != nullptr;
     }
-    if (!tile_q) { launch_scan(s, in, n, bsum, out, total_out); return; }
+    if (!tile_q) { launch_scan(s, in, n, bsum, out, total_out); return false; }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
-        hipLaunchKernelGGL((k_scan_down<true, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0));
-        return;
+        hipLaunchKernelGGL((k_scan_down<true, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0), CounterPub());
+        return false;
     }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL((k_scan_down<true, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0));
+    hipLaunchKernelGGL((k_scan_down<true, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0), CounterPub());
+    return false;
 }
 
 // fill variants, selected at run time (KMX_FILL_VARIANT, see kmx_capi.hip)
