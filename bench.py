@@ -69,6 +69,10 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
     ap.add_argument("--verify", type=int, default=20000, help="queries checked against the oracle after timing")
+    ap.add_argument("--sort-queries", action="store_true",
+                    help="experiment: the shard's queries sorted by rank-hash on the host before upload — the best case of a hash-binned "
+                         "lookup + fill for the READ side (table and arena swept in order); says nothing about the cost of binning or of "
+                         "writing the hit lists back in query order")
     ap.add_argument("--oversubscribe", action="store_true",
                     help="rehearsal only: allow more ranks than visible GPUs (ranks share devices; the exchange runs over gloo because "
                          "RCCL refuses two ranks on one device).  The JSON line says so.")
@@ -196,6 +200,12 @@ def worker(args):
             z = synth.u64_stream(qseed, e - s, rank * nq * m + s)
             qr_host[s:e] = (((z >> np.uint64(32)) * np.uint64(args.sigma)) >> np.uint64(32)).astype(np.uint8)
         qoff_host = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
+        if args.sort_queries:
+            h = np.zeros(nq, np.uint64)
+            q2 = qr_host.reshape(nq, m)
+            for j in range(m):
+                h = h * np.uint64(args.sigma) + q2[:, j]
+            qr_host = np.ascontiguousarray(q2[np.argsort(h, kind="stable")]).reshape(-1)
     else:
         m = 0
         qr_host, qoff_host = synth.mixed_queries(qseed + 7919 * rank, text, nq, qlens, args.sigma, planted_frac=planted)
