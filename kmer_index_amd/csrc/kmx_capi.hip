@@ -337,13 +337,16 @@ kmx_status check_device()
 
 // Cells (KmxElemDev::cnt8) for a dense element with short buckets: log2 of the cell size in positions, or 0 for "no cells".
 // A cell must hold nearly every group — for i.i.d. text the sizes are Poisson(c) with c = npos / sigma^k, and a cell of
-// 8 / 16 / 32 positions leaves < 0.1 % of the keys out up to c = 2 / 6 / 24 — and the cells must not dwarf the index.
+// 8 / 16 / 32 positions leaves about 1 / 4 / 5 % of the keys out at c = 3.5 / 10.5 / 24 (those take one more table read:
+// measured, the smaller cell is as fast as the next larger one — DNA5 k = 10: 16 vs 32 positions, protein k = 5: 8 vs 16 —
+// at two thirds of the memory) — and the cells must not dwarf the index.
 static uint32_t cell_shift_for(uint32_t table_kind, uint64_t n_keys, uint64_t npos, uint64_t region, const kmx_options& o)
 {
     if (table_kind != KMX_TABLE_DENSE || o.no_aligned_copy || region > npos) return 0;     // (long buckets have the aligned copy)
     if (const char* e = getenv("KMX_CELLS")) { if (!atoi(e)) return 0; }
     const double c = double(npos) / double(n_keys);
-    const uint32_t shift = c <= 2.0 ? 3u : c <= 6.0 ? 4u : c <= 24.0 ? 5u : 0u;
+    uint32_t shift = c <= 3.5 ? 3u : c <= 10.5 ? 4u : c <= 24.0 ? 5u : 0u;
+    if (const char* e = getenv("KMX_CELL_SHIFT")) { const int v = atoi(e); if (v >= 3 && v <= 5) shift = uint32_t(v); }   // tuning experiment
     if (!shift) return 0;
     if ((n_keys << shift) > 8 * npos) return 0;               // at most 8x the contiguous copy
     return shift;
