@@ -184,3 +184,40 @@ def test_batches_too_large_for_one_pass_are_streamed_in_chunks(engine, monkeypat
     r5 = idx.search(q, off, result=r1)
     assert _same(r5.host(), want) and r5.counts() == c1
     rc.close(); r5.close(); idx.close()
+
+
+def test_no_device_memory_is_leaked(engine, monkeypatch):
+    """Indexes (with replicas), results of every shape (general, latency path, multi-part, chunked) and the pools behind them give
+    their device memory back: free memory after ten rounds of build / search / free equals what it was after the first."""
+    import torch
+    text = synth.ranks(55, 500_000, 4)
+    q, off = make_queries(text, 4, [6, 8, 10, 13, 20, 25], 300, seed=2)
+
+    def one_round():
+        idx = engine.Index(text, 4, [8, 10], devices=[0, 0], keep_host_arena=True)
+        r = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS)
+        r.host(); r.masks()
+        s = idx.search(q[:int(off[3])], off[:4])
+        s.host()
+        monkeypatch.setenv("KMX_HOST_CHUNK", "500")
+        c = idx.search(q, off)
+        c.host()
+        monkeypatch.delenv("KMX_HOST_CHUNK")
+        one = engine.Index(text, 4, [9], table=engine.TABLE_OPEN)
+        d_q = torch.from_numpy(q).to("cuda:0")
+        d_off = torch.from_numpy(off.view(np.int64)).to("cuda:0")
+        a = one.search_device(d_q.data_ptr(), d_off.data_ptr(), off.size - 1, flags=engine.SEARCH_ASYNC)
+        one.close()                                        # completes the pending search
+        a.host()
+        for x in (r, s, c, a):
+            x.close()
+        idx.close()
+        del d_q, d_off
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        return torch.cuda.mem_get_info(0)[0]
+
+    first = one_round()
+    for _ in range(9):
+        last = one_round()
+    assert abs(first - last) <= 8 << 20, (first, last)
