@@ -1573,9 +1573,27 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     for (size_t r = 0; r <= W; ++r) parent->part_q0[r] = nq / W * r + (nq % W) * r / W;   // == floor(nq * r / W) without the overflow
     if (nq < 256 * W)                                   // a handful of queries: one device, one round trip (the other parts stay empty)
         for (size_t r = 1; r <= W; ++r) parent->part_q0[r] = nq;
+    // one host thread per replica for the first half (input copies from pageable memory are staged by the calling thread:
+    // in turn they would reach the GPUs one after the other, each device waiting for the one before it)
     kmx_status st = KMX_OK;
-    for (size_t r = 0; r < W && st == KMX_OK; ++r)
-        st = search_host_one(ix->replica(r), qranks, qoff, parent->part_q0[r], parent->part_q0[r + 1], flags, &parent->parts[r], false);
+    {
+        std::vector<kmx_status> sts(W, KMX_OK);
+        std::vector<std::string> msgs(W);
+        std::vector<std::thread> threads;
+        size_t busy = 0;
+        for (size_t r = 0; r < W; ++r) busy += parent->part_q0[r + 1] > parent->part_q0[r];
+        auto run = [&](size_t r) {
+            sts[r] = search_host_one(ix->replica(r), qranks, qoff, parent->part_q0[r], parent->part_q0[r + 1], flags, &parent->parts[r], false);
+            if (sts[r] != KMX_OK) msgs[r] = g_err;                       // (g_err is thread-local)
+        };
+        for (size_t r = 0; r < W; ++r) {
+            if (busy > 1 && parent->part_q0[r + 1] > parent->part_q0[r]) threads.emplace_back(run, r);
+            else run(r);
+        }
+        for (auto& t : threads) t.join();
+        for (size_t r = 0; r < W && st == KMX_OK; ++r)
+            if (sts[r] != KMX_OK) st = fail(sts[r], msgs[r]);
+    }
     parent->n_hits = parent->n_exact = parent->n_stitch = parent->n_prefix = parent->n_error = parent->n_none = parent->n_mask_words = 0;
     for (size_t r = 0; r < W; ++r) {
         kmx_result* p = parent->parts[r];
