@@ -365,9 +365,7 @@ def worker(args):
                        "same_hit_total": bool(same2), "how": "two result handles on two HIP streams, KMX_SEARCH_ASYNC"}
         for r_ in res2:
             r_.close()
-    gather_leg = run_gather(idx, args.steps, args.warmup) if want_gather else None
-
-    t_el = torch.tensor([elapsed, gather_leg["elapsed"] if gather_leg else 0.0], dtype=torch.float64, device=comm_dev)
+    t_el = torch.tensor([elapsed], dtype=torch.float64, device=comm_dev)
     total_hits = counts["n_hits"]
     fill = stats.get("k_fill", {"launches": 0, "total_ms": 0.0})
     fill_ms = fill["total_ms"] / max(fill["launches"], 1)
@@ -387,8 +385,6 @@ def worker(args):
                 "ranks_seen": int(dist.get_world_size()), "all_reduce_ok": int(chk.item()) == world * (world + 1) // 2,
                 "devices_visible": n_dev}
     elapsed = float(t_el[0].item())
-    if gather_leg:
-        gather_leg["elapsed"] = float(t_el[1].item())
 
     # ---- the literal north_star variant (open-addressing probe) on the same workload and the same pipeline, outside the timed region ----
     open_leg = None
@@ -451,11 +447,10 @@ def worker(args):
                 sel = lens[qi] > j
                 ok &= bool(np.array_equal(text[pos[sel] + j], qr_host[qoff_host[qi[sel]].astype(np.int64) + j]))
             verified = bool(ok)
-        if gather_leg:                                            # the gathered arrays must account for every shard
-            verified = verified and gather_leg.get("gathered_hits") == total_hits
         if not verified:
             log("VERIFICATION FAILED")
 
+    out = None
     if rank == 0:
         n_total_q = nq * world
         ms_per_step = elapsed / args.steps * 1e3
@@ -489,21 +484,6 @@ def worker(args):
         if per_rank is not None:
             roofline["per_rank_frac"] = [round(8.0 * h / (f * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if f > 0 else 0.0 for f, h, _ in per_rank]
             roofline["per_rank_step_ms"] = [round(e / args.steps * 1e3, 4) for _, _, e in per_rank]
-        gather_out = None
-        if gather_leg:
-            g_ms_step = gather_leg["elapsed"] / args.steps * 1e3
-            peers = [b for b in gather_leg["bytes_per_peer"] if b]
-            per_link = (max(peers) / (gather_leg["gather_ms"] * 1e-3) / 1e9) if peers and gather_leg["gather_ms"] > 0 else 0.0
-            gather_out = {"value": round(n_total_q * args.steps / gather_leg["elapsed"] / 1e6, 3), "unit": "M queries/s",
-                          "ms_per_step": round(g_ms_step, 4), "gather_ms": round(gather_leg["gather_ms"], 4),
-                          "bytes_per_peer_per_step": max(peers) if peers else 0,
-                          "per_link_GBps": round(per_link, 1), "per_link_frac_of_xgmi": round(per_link / XGMI_LINK_GBPS, 4),
-                          "root_ingress_GBps": round(sum(peers) / (gather_leg["gather_ms"] * 1e-3) / 1e9, 1) if peers and gather_leg["gather_ms"] > 0 else 0.0,
-                          "gathered_hits": gather_leg.get("gathered_hits"),
-                          "how": "dist.batch_isend_irecv: one grouped exchange, all peers' links at once, into buffers kept between "
-                                 "steps; the gather of step i overlaps the search of step i+1 (two handles, two compute streams)"}
-        if args.gather == "hits" and gather_out:
-            value, ms_per_step = gather_out["value"], gather_out["ms_per_step"]
         out = {
             "metric": "M queries/sec, DNA4 k=10 exact-match batch search, 1e8-bp text" if args.config == 2 else f"M queries/sec, BASELINE configs[{args.config - 1}] (informational)",
             "value": round(value, 3),
@@ -522,17 +502,76 @@ def worker(args):
                                    f"{'(dense)' if info['tables'][0] == engine.TABLE_DENSE else '(open)'}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
                        "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated",
-                       "gather": "hits" if args.gather == "hits" and gather_out else "totals", "pipeline_depth": depth, "streams": max(1, min(args.streams, depth))},
+                       "gather": "totals", "pipeline_depth": depth, "streams": max(1, min(args.streams, depth))},
             "roofline": roofline,
             "rccl": rccl,
-            "gather_hits": gather_out,
+            "gather_hits": None,
             "two_streams": two_streams,
             "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
             "kernels_avg_ms": kernels_ms,
             "verified_vs_oracle": verified,
         }
+    # ---- leg 2 last, under a deadline: everything `value` needs is already in `out`, so an exchange that fails or
+    # never returns costs the line its gather_hits object (an "error" entry instead) and nothing else ----
+    if want_gather:
+        import threading
+        deadline = float(os.environ.get("KMX_BENCH_GATHER_DEADLINE", "300"))
+        once = threading.Lock()
+
+        def give_up():
+            if not once.acquire(blocking=False):
+                return
+            if rank == 0:
+                out["gather_hits"] = {"error": f"the gather leg did not finish within {deadline:.0f} s; abandoned"}
+                print(json.dumps(out), flush=True)
+            log(f"gather leg abandoned after {deadline:.0f} s")
+            os._exit(0 if (verified is None or verified) else 4)
+
+        guard = threading.Timer(deadline, give_up)
+        guard.daemon = True
+        guard.start()
+        gather_leg, gather_err = None, None
+        try:
+            gather_leg = run_gather(idx, args.steps, args.warmup)
+            t_g = torch.tensor([gather_leg["elapsed"]], dtype=torch.float64, device=comm_dev)
+            dist.all_reduce(t_g, op=dist.ReduceOp.MAX)
+            gather_leg["elapsed"] = float(t_g.item())
+        except Exception as e:                                        # reported, not fatal: leg 1 stands on its own
+            gather_leg, gather_err = None, f"{type(e).__name__}: {e}"
+            log("gather leg failed: " + gather_err)
+        guard.cancel()
+        if not once.acquire(blocking=False):                          # the guard is already printing the line
+            time.sleep(3600)
+        if rank == 0:
+            if gather_leg:
+                n_total_q = nq * world
+                g_ms_step = gather_leg["elapsed"] / args.steps * 1e3
+                peers = [b for b in gather_leg["bytes_per_peer"] if b]
+                per_link = (max(peers) / (gather_leg["gather_ms"] * 1e-3) / 1e9) if peers and gather_leg["gather_ms"] > 0 else 0.0
+                out["gather_hits"] = {
+                    "value": round(n_total_q * args.steps / gather_leg["elapsed"] / 1e6, 3), "unit": "M queries/s",
+                    "ms_per_step": round(g_ms_step, 4), "gather_ms": round(gather_leg["gather_ms"], 4),
+                    "bytes_per_peer_per_step": max(peers) if peers else 0,
+                    "per_link_GBps": round(per_link, 1), "per_link_frac_of_xgmi": round(per_link / XGMI_LINK_GBPS, 4),
+                    "root_ingress_GBps": round(sum(peers) / (gather_leg["gather_ms"] * 1e-3) / 1e9, 1) if peers and gather_leg["gather_ms"] > 0 else 0.0,
+                    "gathered_hits": gather_leg.get("gathered_hits"),
+                    "how": "dist.batch_isend_irecv: one grouped exchange, all peers' links at once, into buffers kept between "
+                           "steps; the gather of step i overlaps the search of step i+1 (two handles, two compute streams)"}
+                if gather_leg.get("gathered_hits") != total_hits:     # the gathered arrays must account for every shard
+                    verified = False
+                    out["verified_vs_oracle"] = False
+                    log("VERIFICATION FAILED: gathered hits != sum of the shards")
+                if args.gather == "hits":
+                    out["value"], out["ms_per_step"] = out["gather_hits"]["value"], out["gather_hits"]["ms_per_step"]
+                    out["config"]["gather"] = "hits"
+            else:
+                out["gather_hits"] = {"error": gather_err}
+    if rank == 0:
         print(json.dumps(out), flush=True)
+    if want_gather and gather_err is not None:                        # the process group may be unusable: no teardown through it
+        sys.stderr.flush()
+        os._exit(0 if (verified is None or verified) else 4)
     for r_ in results:
         r_.close()
     idx.close()

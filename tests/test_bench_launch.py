@@ -81,6 +81,16 @@ def test_two_ranks_under_the_distributed_launcher_rehearsal():
 
 
 @pytest.mark.gpu
+def test_a_gather_leg_that_never_returns_costs_only_its_own_object():
+    """The gather leg runs last under a deadline (KMX_BENCH_GATHER_DEADLINE): when it passes, rank 0 still prints the line —
+    `value`, roofline and verification from the sharded leg, an error entry in place of gather_hits — and every rank exits 0."""
+    rc, out, err = _run(["--gpus", "2", "--oversubscribe"] + SMALL, env_extra={"KMX_BENCH_GATHER_DEADLINE": "0.001"})
+    assert rc == 0, err[-2000:]
+    assert out["n_gpus"] == 2 and out["value"] > 0 and out["verified_vs_oracle"] is True and out["roofline"]["frac"] > 0
+    assert "did not finish" in out["gather_hits"]["error"]
+
+
+@pytest.mark.gpu
 def test_n_ranks_over_rccl_when_the_box_has_the_devices():
     """The real thing: one rank per GPU over RCCL/xGMI.  Skipped (not faked with gloo) on a 1-GPU box."""
     n = _n_devices()
