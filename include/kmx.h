@@ -132,10 +132,14 @@ void kmx_index_free(kmx_index* index);
 
 /* On-disk image of the flattened index: build once, load many (the intent stated in the thesis,
  * thesis/content/02_implementation.tex:44-46; not implemented by the reference).  kmx_index_load validates
- * magic, version, every size field and a checksum, and then the CONTENTS the kernels index with — group boundaries
- * monotone and ending at npos, distinct keys strictly ascending and inside the key space, at most half of the
- * open-addressing slots occupied (a full table would make the probe loop spin), every slot's and every aligned-table
- * entry's run inside the element's region, positions inside the text — before touching the device. */
+ * magic, version, every size field (the file must be exactly as long as its element table says — nothing is
+ * allocated on the word of a header the file cannot back) and a checksum, and then the CONTENTS the kernels index
+ * with — group boundaries monotone and ending at npos, the positions of every group strictly ascending and inside
+ * the text, distinct keys strictly ascending and inside the key space, at most half of the open-addressing slots
+ * occupied (a full table would make the probe loop spin), every slot naming exactly the group of its key, the
+ * aligned copy restating the groups, the text tail inside the alphabet — before touching the device.  An image
+ * that loads can be searched without harm whatever else it holds (tests/test_image_cpu.py, test_image_gpu.py:
+ * mutation fuzz). */
 kmx_status kmx_index_save(const kmx_index* index, const char* path);
 kmx_status kmx_index_load(const char* path, const kmx_options* opts, kmx_index** out);
 

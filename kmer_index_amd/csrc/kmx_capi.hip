@@ -1996,6 +1996,22 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
         kmax = std::max(kmax, fe.k);
     }
     if (kmax != fh.kmax) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: corrupt header (kmax)");
+    {
+        // The element table promises sizes; nothing is allocated on its word before the file is seen to hold exactly
+        // that much (a 60-byte file may not ask for 16 GB of positions or a 2^40-slot table).
+        const long here = ftell(f);
+        if (here < 0 || fseek(f, 0, SEEK_END) != 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: cannot size the file");
+        const long end = ftell(f);
+        if (end < here || fseek(f, here, SEEK_SET) != 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: cannot size the file");
+        const uint64_t left = uint64_t(end - here);
+        auto pad8 = [](unsigned __int128 b) { return (b + 7) / 8 * 8; };
+        unsigned __int128 want = pad8(fh.kmax);
+        for (const FileElem& fe : fes)
+            want += pad8((unsigned __int128)fe.region * 4) + pad8((unsigned __int128)fe.n_offs * 4) + pad8((unsigned __int128)fe.n_aoffs * 4) +
+                    pad8((unsigned __int128)fe.n_slots * sizeof(KmxSlot)) + pad8((unsigned __int128)fe.n_ukeys * 8);
+        if (want != left)
+            return fail(KMX_ERR_INVALID_ARGUMENT, want > left ? "kmx_index_load: truncated file" : "kmx_index_load: the file is longer than its element table says");
+    }
     std::vector<uint8_t> tail(fh.kmax);
     if (!read_section(f, mx, tail.data(), tail.size())) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
     std::vector<kmx::ElemImage> images(fh.n_ks);
@@ -2015,6 +2031,8 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
             return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: truncated file");
     }
     if (mx.h != fh.checksum) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: checksum mismatch (corrupt image)");
+    for (uint8_t c : tail)
+        if (c >= fh.sigma) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_load: corrupt contents: a letter of the text tail is outside the alphabet");
     // The checksum is not cryptographic and says nothing about an image that was WRITTEN wrong: check what the kernels
     // index with.  A full slot table would make probe() spin for ever, an offset past the region reads out of bounds.
     for (uint32_t i = 0; i < fh.n_ks; ++i) {
@@ -2026,6 +2044,9 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
         const uint64_t last_start = fh.n - im.k;
         for (uint64_t j = 0; j < im.npos; ++j)
             if (im.positions[j] > last_start) return bad("a position lies outside the text");
+        for (size_t j = 0; j + 1 < im.offs.size(); ++j)                  // the kernels search and merge groups as sorted runs
+            for (uint64_t t = uint64_t(im.offs[j]) + 1; t < im.offs[j + 1]; ++t)
+                if (im.positions[t] <= im.positions[t - 1]) return bad("the positions of a group are not strictly ascending");
         if (im.table_kind == KMX_TABLE_OPEN) {
             const uint64_t cap = uint64_t(1) << im.log2cap;
             if (2 * uint64_t(im.ukeys.size()) > cap) return bad("the open-addressing table is more than half full");
@@ -2038,6 +2059,9 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
                 if (!sl.cnt) continue;
                 ++used;
                 if (sl.key >= im.n_keys || uint64_t(sl.off) + sl.cnt > im.region) return bad("a slot points outside the element's region");
+                const size_t g = size_t(std::lower_bound(im.ukeys.begin(), im.ukeys.end(), sl.key) - im.ukeys.begin());
+                if (g == im.ukeys.size() || im.ukeys[g] != sl.key || sl.off != im.offs[g] || sl.cnt != im.offs[g + 1] - im.offs[g])
+                    return bad("a slot does not name the group of its key");
             }
             if (used != im.ukeys.size()) return bad("occupied slots and distinct keys differ in number");
         } else if (!im.atab.empty()) {
@@ -2046,6 +2070,14 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
                 if (j && (im.atab[j] & ~31u) < (im.atab[j - 1] & ~31u)) return bad("the aligned table is not monotone");
             }
             if ((im.atab.front() & ~31u) < im.npos) return bad("the aligned copy overlaps the contiguous copy");
+            for (size_t j = 0; j + 1 < im.atab.size(); ++j) {             // the aligned copy restates the groups, nothing else
+                const uint32_t e0 = im.atab[j], e1 = im.atab[j + 1];
+                const uint32_t padded = (e1 & ~31u) - (e0 & ~31u), r = e0 & 31u;
+                const uint32_t c = padded ? (r ? padded - 32u + r : padded) : 0u;      // atab_count() of the kernels
+                if (c != im.offs[j + 1] - im.offs[j] || uint64_t(e0 & ~31u) + c > im.region ||
+                    (c && memcmp(&im.positions[e0 & ~31u], &im.positions[im.offs[j]], size_t(c) * 4) != 0))
+                    return bad("the aligned copy of a group differs from the group");
+            }
         }
     }
     kmx_status st = check_device();
