@@ -1559,6 +1559,7 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
     int caller_device = 0;
     (void)hipGetDevice(&caller_device);
     kmx_result* parent = *out;
+    if (parent && parent->chunked) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle belongs to a chunk-streamed search of another index");
     if (parent && parent->parts.size() != W) {
         if (!parent->parts.empty() || parent->device_bytes()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle was made by a search of another shape");
     }

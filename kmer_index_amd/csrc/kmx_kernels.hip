@@ -771,6 +771,30 @@ __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict_
     return good;
 }
 
+// Membership of NR values per lane in the sorted bucket staged at `arr` (padded with 0xFFFFFFFF to the power of two P):
+// lower_bound (:283 binary_search, :544-546) as log2(P) branch-free halving steps, the NR searches in lockstep so that
+// their LDS reads overlap.  Bit r of the result: x[r] is in the bucket.
+template <int NR>
+__device__ __forceinline__ uint32_t staged_members(const uint32_t* __restrict__ arr, uint32_t P, const uint32_t (&x)[KMX_VCH])
+{
+    uint32_t pos[NR], tv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pos[r] = 0;
+    for (uint32_t st = P >> 1; st; st >>= 1) {
+        const uint32_t* __restrict__ probe_at = arr + (st - 1);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) tv[r] = probe_at[pos[r]];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pos[r] += tv[r] < x[r] ? st : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < NR; ++r) tv[r] = arr[pos[r]];
+    uint32_t m = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) m |= uint32_t(tv[r] == x[r]) << r;
+    return m;
+}
+
 // INLINE_MORE: the survivors' further parts are checked right here (more registers, and the groups of a wave wait
 // for each other's survivors); otherwise k_validate_more does it afterwards from the survivor lists.
 template <bool INLINE_MORE>
@@ -818,14 +842,13 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         max_it = uint32_t(__builtin_amdgcn_readfirstlane(int(max_it)));
         uint32_t* __restrict__ arr = stage[wv][g];
         {
-            const uint32_t nb = staged ? pcnt : 0u;
-            for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_VGROUP) {     // straight-line loads: dead slots read arena[0]
+            // straight-line loads through one pointer per lane; a slot past the bucket re-reads its last entry
+            const uint32_t nb = staged ? pcnt : 0u, last = nb ? nb - 1u : 0u;
+            const uint32_t* __restrict__ fil = arena + p1src;
+            for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_VGROUP) {
                 uint32_t v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t t = t0 + uint32_t(j) * KMX_VGROUP + gl;
-                    v[j] = arena[t < nb ? p1src + t : 0];
-                }
+                for (int j = 0; j < 4; ++j) v[j] = fil[min(t0 + uint32_t(j) * KMX_VGROUP + gl, last)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const uint32_t t = t0 + uint32_t(j) * KMX_VGROUP + gl;
@@ -838,41 +861,38 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         uint32_t w_lo = 0, w_hi = 0, valid = 0;
+        const uint32_t* __restrict__ cand = arena + src;
+        const uint32_t c_last = (fast && c0) ? c0 - 1u : 0u;
+        const bool unstaged = fast && !staged;
         // KMX_VCH rounds of 16 candidates at a time: their loads go out together and their searches advance
         // in lockstep, so one global and log2(P) + 1 LDS round trips are exposed per chunk instead of per round
         for (uint32_t it0 = 0; it0 < max_it; it0 += KMX_VCH) {
             const uint32_t nr = min(uint32_t(KMX_VCH), max_it - it0);  // wave-uniform
-            uint32_t x[KMX_VCH], pos[KMX_VCH], tv[KMX_VCH];
+            const uint32_t ci0 = it0 * KMX_VGROUP + gl;
+            uint32_t x[KMX_VCH];
 #pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r) {
-                const uint32_t ci = (it0 + uint32_t(r)) * KMX_VGROUP + gl;
-                x[r] = arena[(fast && ci < c0) ? src + ci : 0];        // dead slots read arena[0]
-                pos[r] = 0;
-            }
+            for (int r = 0; r < KMX_VCH; ++r) x[r] = cand[min(ci0 + uint32_t(r) * KMX_VGROUP, c_last)];   // dead slots re-read the last candidate
 #pragma unroll
             for (int r = 0; r < KMX_VCH; ++r) x[r] += delta;
-            for (uint32_t st = P >> 1; st; st >>= 1) {                 // lower_bound (:283 binary_search, :544-546)
-#pragma unroll
-                for (int r = 0; r < KMX_VCH; ++r)
-                    if (uint32_t(r) < nr) tv[r] = arr[pos[r] + st - 1];
-#pragma unroll
-                for (int r = 0; r < KMX_VCH; ++r)
-                    if (uint32_t(r) < nr) pos[r] += tv[r] < x[r] ? st : 0u;
+            // bit r: this lane has a candidate in round r
+            const uint32_t n_live = (fast && ci0 < c0) ? min(uint32_t(KMX_VCH), (c0 - ci0 + KMX_VGROUP - 1) / KMX_VGROUP) : 0u;
+            const uint32_t livem = (1u << n_live) - 1u;
+            uint32_t okm;                                               // bit r: this lane's candidate of round r holds so far
+            switch ((nr + 1) >> 1) {                                    // (straight-line code for 2, 4, 6 or 8 rounds)
+                case 1: okm = staged_members<2>(arr, P, x); break;
+                case 2: okm = staged_members<4>(arr, P, x); break;
+                case 3: okm = staged_members<6>(arr, P, x); break;
+                default: okm = staged_members<8>(arr, P, x); break;
             }
-#pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r)
-                if (uint32_t(r) < nr) tv[r] = arr[pos[r]];
-            uint32_t okm = 0;                                           // bit r: this lane's candidate of round r holds so far
-#pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r) {
-                if (uint32_t(r) >= nr) break;
-                const bool live = fast && (it0 + uint32_t(r)) * KMX_VGROUP + gl < c0;
-                bool hit = tv[r] == x[r];
-                if (live && !staged) {                                  // bucket too long for LDS
-                    const uint64_t lb = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x[r]);
-                    hit = lb < pcnt && arena[p1src + lb] == x[r];
+            okm &= livem;
+            if (__any(unstaged)) {                                      // a filter bucket too long for LDS: searched where it lies
+                if (unstaged) {
+                    okm = 0;
+                    for (uint32_t r = 0; r < n_live; ++r) {
+                        const uint64_t lb = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x[r]);
+                        okm |= uint32_t(lb < pcnt && arena[p1src + lb] == x[r]) << r;
+                    }
                 }
-                okm |= uint32_t(live && hit) << r;
             }
             if (INLINE_MORE && __any(more && okm != 0)) {
                 // queries with further parts: the survivors of the filter, one per group at a time
@@ -904,7 +924,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                 const uint32_t s16 = (half >> ((g & 1) * 16)) & 0xFFFFu;
                 // survivors, already compacted and ascending: what k_fill copies out for this query
                 if (ok && d.stitch_hits)
-                    d.stitch_hits[sbase + valid + uint32_t(__popc(s16 & ((1u << gl) - 1u)))] = arena[src + uint64_t(it) * KMX_VGROUP + gl];
+                    d.stitch_hits[sbase + valid + uint32_t(__popc(s16 & ((1u << gl) - 1u)))] = x[r] - delta;
                 valid += uint32_t(__popc(s16));
                 const uint32_t slice = s16 << ((it & 1) * 16);
                 if (it & 2) w_hi |= slice; else w_lo |= slice;
