@@ -860,7 +860,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        uint32_t w_lo = 0, w_hi = 0, valid = 0;
+        uint32_t valid = 0;
+        const uint32_t lt_mask = (1u << gl) - 1u;
         const uint32_t* __restrict__ cand = arena + src;
         const uint32_t c_last = (fast && c0) ? c0 - 1u : 0u;
         const bool unstaged = fast && !staged;
@@ -913,25 +914,24 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                     if ((dropped >> gl) & 1u) okm &= ~(1u << r);
                 }
             }
+            // 64 candidates = one bitset word = four rounds of 16-bit ballot slices; a chunk of KMX_VCH = 8 rounds is two
+            // words, and it0 is a multiple of 8, so which half-word a round fills is known at compile time
+            static_assert(KMX_VCH == 8, "the two-words-per-chunk assembly below");
+            uint32_t wq[4] = {0u, 0u, 0u, 0u};                          // {word A low, A high, word B low, B high}
+            uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + sbase : nullptr;
 #pragma unroll
             for (int r = 0; r < KMX_VCH; ++r) {
                 if (uint32_t(r) >= nr) break;
-                const uint32_t it = it0 + uint32_t(r);
-                const bool ok = (okm >> r) & 1u;
-                // 64 candidates = one bitset word = four rounds of 16-bit ballot slices
-                const uint64_t bal = __ballot(ok);
-                const uint32_t half = (g & 2) ? uint32_t(bal >> 32) : uint32_t(bal);
-                const uint32_t s16 = (half >> ((g & 1) * 16)) & 0xFFFFu;
+                const bool ok = (okm & (1u << r)) != 0;
+                const uint32_t s16 = uint32_t(__ballot(ok) >> (KMX_VGROUP * g)) & 0xFFFFu;
                 // survivors, already compacted and ascending: what k_fill copies out for this query
-                if (ok && d.stitch_hits)
-                    d.stitch_hits[sbase + valid + uint32_t(__popc(s16 & ((1u << gl) - 1u)))] = x[r] - delta;
+                if (ok && sh_out) sh_out[valid + uint32_t(__popc(s16 & lt_mask))] = x[r] - delta;
                 valid += uint32_t(__popc(s16));
-                const uint32_t slice = s16 << ((it & 1) * 16);
-                if (it & 2) w_hi |= slice; else w_lo |= slice;
-                if (it < n_it && ((it & 3) == 3 || it + 1 == n_it)) {
-                    if (gl == 0) words[it >> 2] = (uint64_t(w_hi) << 32) | w_lo;   // bit i = word i>>6, bit i&63
-                    w_lo = w_hi = 0;
-                }
+                wq[r >> 1] |= s16 << ((r & 1) * 16);
+            }
+            if (gl == 0) {                                              // bit i = word i>>6, bit i&63
+                if (it0 < n_it) words[it0 >> 2] = (uint64_t(wq[1]) << 32) | wq[0];
+                if (it0 + 4 < n_it) words[(it0 >> 2) + 1] = (uint64_t(wq[3]) << 32) | wq[2];
             }
         }
         if (fast && gl == 0) {
