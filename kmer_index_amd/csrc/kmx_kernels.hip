@@ -66,6 +66,8 @@ __device__ __forceinline__ const KMX_GLOBAL T* as_global(const T* p)
     return (const KMX_GLOBAL T*)p;
 }
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
 // plan[m] as one 32-bit load ({u8 scheme, u8 elem, u16 nparts}, little endian)
 __device__ __forceinline__ KmxPlanEntry load_plan(const KmxIndexDev* __restrict__ ix, uint64_t m)
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                                                         const uint64_t* __restrict__ qoff, QueryDesc d,
                                                         uint64_t n_stitch, uint64_t* __restrict__ mask_words)
 {
-    __shared__ uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VSTAGE];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VSTAGE];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x / KMX_WAVE;
     const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
@@ -815,13 +817,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
     for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
         const uint64_t i = i0 + g;
         const bool have = i < n_stitch;
-        const uint32_t q = have ? d.stitch_list[i] : 0u;
+        // straight-line loads: a group past the end of the list reads the list's last query and is masked by `have`
+        const uint32_t q = d.stitch_list[min(i, n_stitch - 1)];
         // one round of independent loads per group
-        const uint32_t c0 = have ? d.c0[q] : 0u;
-        const uint64_t src = have ? (d.src[q] & ~SRC_FLAGS) : 0;
-        const uint64_t p1 = have ? d.p1[q] : 0;
-        const uint64_t p1src = have ? d.key[q] : 0;
-        const uint64_t wbase = have ? d.aux[q] : 0;
+        const uint32_t c0 = d.c0[q];
+        const uint64_t src_raw = d.src[q];
+        const uint64_t p1 = d.p1[q];
+        const uint64_t p1src = d.key[q];
+        const uint64_t wbase = d.aux[q];
+        const uint64_t src = src_raw & ~SRC_FLAGS;
         uint64_t* __restrict__ words = mask_words + wbase;
         const uint64_t sbase = wbase * 64;
         const bool fast = have && (INLINE_MORE || !(p1 & KMX_P1_BIG));  // (big queries: validate_big_wave, from k_validate_more)
@@ -842,18 +846,19 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         max_it = uint32_t(__builtin_amdgcn_readfirstlane(int(max_it)));
         uint32_t* __restrict__ arr = stage[wv][g];
         {
-            // straight-line loads through one pointer per lane; a slot past the bucket re-reads its last entry
+            // four consecutive entries per lane and step: one 16-byte load (any element of the arena may be read 16 bytes
+            // wide: its allocation is padded), one 16-byte LDS store; a lane past the bucket re-reads its last entry.
+            // Whole 64-entry steps are written (a group's array has room for KMX_VSTAGE = 256 >= P rounded up to 64).
             const uint32_t nb = staged ? pcnt : 0u, last = nb ? nb - 1u : 0u;
             const uint32_t* __restrict__ fil = arena + p1src;
             for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_VGROUP) {
-                uint32_t v[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = fil[min(t0 + uint32_t(j) * KMX_VGROUP + gl, last)];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t t = t0 + uint32_t(j) * KMX_VGROUP + gl;
-                    if (t < P) arr[t] = t < nb ? v[j] : 0xFFFFFFFFu;
-                }
+                const uint32_t t = t0 + 4u * gl;
+                u32x4 v = *reinterpret_cast<const u32x4_a4*>(fil + min(t, last));
+                v.x = t + 0 < nb ? v.x : 0xFFFFFFFFu;
+                v.y = t + 1 < nb ? v.y : 0xFFFFFFFFu;
+                v.z = t + 2 < nb ? v.z : 0xFFFFFFFFu;
+                v.w = t + 3 < nb ? v.w : 0xFFFFFFFFu;
+                *reinterpret_cast<u32x4*>(arr + t) = v;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
