@@ -411,7 +411,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
     {
         void* p = prebuilt_arena;                             // device-built elements already sit in it
         if (!p) {
-            hipError_t e = hipMalloc(&p, arena_elems * 4 + 64);   // padded: k_fill reads 16 bytes at any element
+            hipError_t e = hipMalloc(&p, arena_elems * 4 + KMX_ARENA_PAD);   // padded: k_fill reads 16 bytes at any element
             if (e != hipSuccess) { fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); return bail(KMX_ERR_OUT_OF_MEMORY); }
         }
         ix->allocs.push_back(p);
@@ -567,7 +567,7 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
     };
     KmxIndexDev h = src->h_header;
     const void* p = nullptr;
-    if (!clone(src->h_header.arena, h.arena_elems * 4 + 64, 0, &p)) return bail(st);
+    if (!clone(src->h_header.arena, h.arena_elems * 4 + KMX_ARENA_PAD, 0, &p)) return bail(st);
     h.arena = static_cast<const uint32_t*>(p); ix->d_arena = h.arena;
     if (!clone(src->h_header.tail, h.kmax, 16, &p)) return bail(st);
     h.tail = static_cast<const uint8_t*>(p);
@@ -881,11 +881,11 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
         if (cs) arena_elems = up32(arena_elems) + (images[i].n_keys << cs);
     }
     {
-        hipError_t e = hipMalloc(&arena, arena_elems * 4 + 64);      // padded: kernels read 16 bytes at any element
+        hipError_t e = hipMalloc(&arena, arena_elems * 4 + KMX_ARENA_PAD);      // padded: kernels read 16 bytes at any element
         if (e != hipSuccess) { free_dev(); return fail(KMX_ERR_OUT_OF_MEMORY, std::string("arena: ") + hipGetErrorString(e)); }
         // the padding between line-aligned groups is never written by the build kernels: defined contents (the image on
         // disk and the host mirror of the arena see it)
-        e = hipMemset(arena, 0, arena_elems * 4 + 64);
+        e = hipMemset(arena, 0, arena_elems * 4 + KMX_ARENA_PAD);
         if (e != hipSuccess) { free_dev(); (void)hipFree(arena); return fail(KMX_ERR_HIP, std::string("arena: ") + hipGetErrorString(e)); }
     }
     auto free_sparse = [&] {

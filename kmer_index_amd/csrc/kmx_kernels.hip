@@ -876,8 +876,12 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
             const uint32_t nr = min(uint32_t(KMX_VCH), max_it - it0);  // wave-uniform
             const uint32_t ci0 = it0 * KMX_VGROUP + gl;
             uint32_t x[KMX_VCH];
+            // one pointer per lane and chunk, clamped to the bucket's last entry; the rounds are immediate offsets from it
+            // (a dead slot reads at most 7 x 16 entries past the bucket: inside the arena's KMX_ARENA_PAD)
+            static_assert((KMX_VCH - 1) * KMX_VGROUP * 4 + 16 <= KMX_ARENA_PAD, "the dead slots of a chunk must stay inside the arena's padding");
+            const uint32_t* __restrict__ cp = cand + min(ci0, c_last);
 #pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r) x[r] = cand[min(ci0 + uint32_t(r) * KMX_VGROUP, c_last)];   // dead slots re-read the last candidate
+            for (int r = 0; r < KMX_VCH; ++r) x[r] = cp[r * KMX_VGROUP];
 #pragma unroll
             for (int r = 0; r < KMX_VCH; ++r) x[r] += delta;
             // bit r: this lane has a candidate in round r
