@@ -726,7 +726,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 // e-th summand of _optimal_nk_sum[m] counted from the end (:532-555).  Returns this lane's verdict.
 __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict__ ix, const uint32_t* __restrict__ arena,
                                                   const uint8_t* __restrict__ qranks, const uint64_t* __restrict__ qoff,
-                                                  uint32_t q, uint32_t p, uint32_t gl, uint32_t stride = KMX_VGROUP)
+                                                  uint32_t q, uint32_t p, uint32_t gl, uint32_t stride = KMX_VGROUP,
+                                                  uint32_t skip_start = 0xFFFFFFFFu)
 {
     const uint64_t b = qoff[q];
     const uint64_t m = qoff[q + 1] - b;
@@ -742,6 +743,7 @@ __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict_
         const uint32_t n_extra = P - 1 + ((m % k) ? 1 : 0);
         for (uint32_t e = gl; e < n_extra && good; e += stride) {
             const uint64_t start = (e < P - 1) ? uint64_t(e + 1) * k : (m - k);
+            if (uint32_t(start) == skip_start) continue;               // (the caller has this part's verdict already)
             uint64_t h;
             rank_hash(qr + start, k, sigma, h, qend);
             const Run r = probe(el, h);
@@ -762,6 +764,7 @@ __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict_
                 k = el->k;
                 mm -= k;                                               // this summand covers [mm, mm + k)
             }
+            if (uint32_t(mm) == skip_start) continue;
             uint64_t h;
             rank_hash(qr + mm, k, sigma, h, qend);
             const Run r = probe(el, h);                                // search_k, :520
@@ -1265,6 +1268,59 @@ __device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint
         }
     }
     if (lane == 0) d.cnt[q] = kept;
+}
+
+// k_validate_more_thread — the same check as k_validate_more with one THREAD per query, for queries with few further parts
+// (reads a little longer than 2k: m = 25 at k = 10 has ONE part beyond the filter).  A 16-lane group per survivor has work
+// for as many lanes as there are parts, and every part is a chain of dependent loads (letters, table, log2(bucket) probes):
+// with 2 of 16 lanes busy the kernel is short of loads in flight, not of bandwidth.  Here every lane carries a query; the
+// part k_validate filtered with is not looked at again.  A handled query loses its KMX_P1_MORE flag, which is what
+// k_validate_more and k_validate_wave (launched behind this kernel for the queries it leaves) select by.
+#define KMX_VMORE_THREAD_PARTS 4          // further parts up to which a query takes this path ...
+#define KMX_VMORE_THREAD_PARTS_MANY 10    // ... and in a batch with at least KMX_VMORE_THREAD_MANY such queries (enough threads to
+#define KMX_VMORE_THREAD_MANY (1u << 18)  //     hide a chain that is parts times as long: 100-letter reads at k = 10, 2e6 of them)
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate_more_thread(const KmxIndexDev* __restrict__ ix,
+                                                                    const uint32_t* __restrict__ arena,
+                                                                    const uint8_t* __restrict__ qranks,
+                                                                    const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                                    uint64_t n_stitch, uint32_t max_parts,
+                                                                    uint64_t* __restrict__ mask_words)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (i >= n_stitch) return;
+    const uint32_t q = d.stitch_list[i];
+    const uint64_t p1 = d.p1[q];
+    if ((p1 & KMX_P1_BIG) || !(p1 & KMX_P1_MORE)) return;
+    const uint32_t tentative = d.cnt[q];
+    if (tentative == 0 || tentative > KMX_VMORE_WAVE) return;
+    const uint64_t m = qoff[q + 1] - qoff[q];
+    const KmxPlanEntry pe = load_plan(ix, m);
+    uint32_t n_extra;
+    if (pe.scheme == KMX_SCHEME_SINGLE) {
+        const uint32_t k = ix->elems[pe.elem].k;
+        n_extra = uint32_t(m / k) - 1u + ((m % k) ? 1u : 0u);
+    } else {
+        n_extra = pe.nparts - 1u;
+    }
+    if (n_extra > max_parts) return;
+    const uint32_t delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
+    const uint64_t wbase = d.aux[q];
+    uint32_t* __restrict__ hits = d.stitch_hits + wbase * 64;
+    uint32_t kept = 0;
+    for (uint32_t t = 0; t < tentative; ++t) {
+        const uint32_t p = hits[t];
+        if (stitch_parts_hold(ix, arena, qranks, qoff, q, p, 0u, 1u, delta)) {
+            if (kept != t) hits[kept] = p;
+            ++kept;
+        } else {
+            // the candidates are ascending: the survivor's index is its rank in the first part's bucket
+            const uint64_t src = d.src[q] & ~SRC_FLAGS;
+            const uint64_t idx = lower_bound_dev<uint32_t>(arena + src, d.c0[q], p);
+            mask_words[wbase + (idx >> 6)] &= ~(uint64_t(1) << (idx & 63));
+        }
+    }
+    d.cnt[q] = kept;
+    d.p1[q] = p1 & ~KMX_P1_MORE;
 }
 
 // k_validate_more — STITCH queries with further parts beyond the filter of k_validate<false>: every survivor
@@ -2367,6 +2423,8 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
     }
     hipLaunchKernelGGL(k_validate<false>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
     if (n_more) {
+        hipLaunchKernelGGL(k_validate_more_thread, dim3(blocks_for(n_stitch, KMX_BLOCK)), block, 0, s, ix, arena, qranks, qoff, d, n_stitch,
+                           uint32_t(n_more >= KMX_VMORE_THREAD_MANY ? KMX_VMORE_THREAD_PARTS_MANY : KMX_VMORE_THREAD_PARTS), mask_words);
         hipLaunchKernelGGL(k_validate_more, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
         const uint64_t wwaves = (n_stitch + KMX_VWAVE_SCAN - 1) / KMX_VWAVE_SCAN;
         const unsigned int wblocks = (unsigned int)std::min<uint64_t>((wwaves + 3) / 4, 256 * 16);

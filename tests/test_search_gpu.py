@@ -346,6 +346,57 @@ def test_multi_part_survivors_are_dropped_from_hits_and_masks(engine, orc):
         assert np.array_equal(rc.host()[0], ho)
 
 
+def test_many_reads_with_few_to_ten_parts_take_the_thread_per_query_check(engine, orc):
+    """k_validate_more_thread: in a batch with >= 2^18 multi-part queries, those with up to 10 further parts are checked one
+    THREAD per query (up to 4 parts in any batch).  Reads of 26..66 letters against k = 6 (5..11 parts), half of them with one
+    letter changed — the true start passes the filter part and fails another one, so survivors are dropped from the hit list,
+    the count and the mask words.  Against the oracle in full, masks against hits on a sample."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    n, k, nq = 300_000, 6, 300_000
+    text = synth.ranks(4242, n, 4)
+    lens = rng.integers(26, 67, nq)
+    starts = rng.integers(0, n - 70, nq)
+    off = np.zeros(nq + 1, np.uint64)
+    np.cumsum(lens, out=off[1:])
+    rep = np.repeat(np.arange(nq), lens)
+    within = np.arange(int(off[-1])) - np.repeat(off[:-1].astype(np.int64), lens)
+    qr = text[starts[rep] + within].copy()
+    changed = np.nonzero(rng.random(nq) < 0.5)[0]
+    at = off[changed].astype(np.int64) + (rng.random(changed.size) * lens[changed]).astype(np.int64)
+    qr[at] = (qr[at] + 1 + rng.integers(0, 3, changed.size)) % 4
+    idx = engine.Index(text, 4, [k], keep_host_arena=True)
+    r = idx.search(qr, off, flags=engine.SEARCH_KEEP_MASKS)
+    ho, pos, st, kd = r.host()
+    assert (kd == engine.KIND_STITCH).sum() > (1 << 18)
+    oidx = orc.Index(text, 4, [k])
+    o_off, o_pos, o_st, _ = oidx.search_batch(qr, off, n_threads=8)
+    assert np.array_equal(st, o_st.astype(np.uint8))
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    base, words_ptr, cand_cnt, cand_src = r.masks()
+    arena = idx.arena_host()
+    for i in rng.integers(0, nq, 3000):
+        if kd[i] != engine.KIND_STITCH:
+            continue
+        nw = int(cand_cnt[i]) // 64 + 1
+        words = np.ctypeslib.as_array(C.cast(words_ptr, C.POINTER(C.c_uint64)), shape=(int(base[i]) + nw,))[int(base[i]):]
+        bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:cand_cnt[i]].astype(bool)
+        cands = arena[int(cand_src[i]):int(cand_src[i]) + int(cand_cnt[i])]
+        assert np.array_equal(cands[bits], pos[int(ho[i]):int(ho[i + 1])]), i
+    # the same batch without masks (survivor lists only) and count-only
+    r2 = idx.search(qr, off)
+    assert np.array_equal(r2.host()[0], ho) and np.array_equal(r2.host()[1], pos)
+    rc = idx.search(qr, off, flags=engine.SEARCH_COUNT_ONLY)
+    assert np.array_equal(rc.host()[0], ho)
+    # a small batch of the same reads (group-per-survivor path for the long ones) agrees
+    sub = 5000
+    r3 = idx.search(qr[:int(off[sub])], off[:sub + 1])
+    assert np.array_equal(r3.host()[0], ho[:sub + 1]) and np.array_equal(r3.host()[1], pos[:int(ho[sub])])
+    for x in (r, r2, rc, r3):
+        x.close()
+    idx.close()
+
+
 def test_concurrent_host_threads_share_one_index(engine, orc):
     """kmx.h: one index may be searched from several host threads at once (search() is const in the reference,
     kmer_index.hpp:505).  Host-buffer calls serialise on the index's internal stream; device-buffer calls run on
