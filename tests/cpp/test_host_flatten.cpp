@@ -2,6 +2,7 @@
 // tests/test_host_cpp.py: the flattened image of one element — kmer_index_element::create, kmer_index.hpp:154-179 —
 // against a std::map of buckets built the obvious way, for every table kind, with and without the line-aligned
 // copy, histogram and sort based, including the largest valid k of an alphabet ((2, 63): key space 2^63).
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <map>
@@ -111,6 +112,50 @@ int main()
         CHECK(!kmx::flatten_element(t.data(), t.size(), 4, 0, KMX_TABLE_AUTO, im, err, true));
         CHECK(!kmx::flatten_element(t.data(), t.size(), 4, 20, KMX_TABLE_DENSE, im, err, true));
         CHECK(kmx::key_space(2, 63) == (uint64_t(1) << 63) && kmx::fast_pow(2, 63) == 0);     // fast_pow.hpp:19
+    }
+    // the planner (choose_search_scheme, kmer_index.hpp:407-476) and choose_best_k (choose_best_k.hpp:12-60) over random
+    // k sets and ranges: every table entry is usable as the kernels use it, whatever the inputs
+    {
+        std::mt19937_64 prng(20261);
+        for (int round = 0; round < 400; ++round) {
+            std::vector<uint32_t> ks;
+            const uint32_t n_ks = 1 + uint32_t(prng() % 5);
+            while (ks.size() < n_ks) {
+                const uint32_t k = 1 + uint32_t(prng() % 31);
+                if (std::find(ks.begin(), ks.end(), k) == ks.end()) ks.push_back(k);
+            }
+            const uint32_t range = round < 40 ? 1 + uint32_t(round) : 1 + uint32_t(prng() % 3000);
+            g_case = "plan round " + std::to_string(round) + " range " + std::to_string(range);
+            const kmx::Plan p = kmx::make_plan(ks, range);
+            const std::vector<KmxPlanEntry> e = kmx::make_plan_entries(ks, range);
+            CHECK(p.use_multi.size() == range && p.nk_sum.size() == range && e.size() == range);
+            for (uint32_t q = 0; q < range; ++q) {
+                CHECK(!p.nk_sum[q].empty());
+                uint64_t sum = 0;
+                for (uint32_t k : p.nk_sum[q]) { sum += k; CHECK(std::find(ks.begin(), ks.end(), k) != ks.end()); }
+                if (p.use_multi[q]) CHECK(sum == q);                              // a chain of summands covers the query exactly
+                else CHECK(p.nk_sum[q].size() == 1);
+                CHECK(e[q].elem < ks.size());
+                CHECK(e[q].scheme == KMX_SCHEME_SINGLE || e[q].scheme == KMX_SCHEME_MULTI);
+                if (e[q].scheme == KMX_SCHEME_MULTI) {
+                    CHECK(ks.size() > 1 && e[q].nparts == p.nk_sum[q].size() && ks[e[q].elem] == p.nk_sum[q].back());
+                    CHECK(q >= ks[e[q].elem]);                                    // the kernels walk q -= k down the chain
+                    if (q > ks[e[q].elem]) CHECK(e[q - ks[e[q].elem]].scheme == KMX_SCHEME_MULTI || p.nk_sum[q].size() == 1);
+                } else {
+                    CHECK(e[q].nparts == 1);
+                }
+            }
+            std::vector<uint64_t> lengths(prng() % 50);
+            for (auto& l : lengths) l = prng() % (round % 3 == 0 ? 40 : 100000);
+            for (uint32_t n_k : {0u, 1u, 3u, 10u, 25u}) {
+                const std::vector<uint32_t> best = kmx::choose_best_k(lengths.empty() ? nullptr : lengths.data(), lengths.size(), n_k);
+                CHECK(best.size() == std::min<size_t>(n_k, 10));
+                for (size_t i = 0; i < best.size(); ++i) {
+                    CHECK(best[i] >= 10 && best[i] <= 29);
+                    for (size_t j = 0; j < i; ++j) CHECK(best[i] != best[j]);
+                }
+            }
+        }
     }
     if (failures) { std::printf("%d failure(s)\n", failures); return 1; }
     std::printf("host flatten ok\n");
