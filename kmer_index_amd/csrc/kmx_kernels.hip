@@ -65,6 +65,7 @@ __device__ __forceinline__ const KMX_GLOBAL T* as_global(const T* p)
 {
     return (const KMX_GLOBAL T*)p;
 }
+#define KMX_LDS __attribute__((address_space(3)))      // a pointer that is KNOWN to point into LDS (ds_read, not flat_load)
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -2260,6 +2261,88 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
             for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][t];
             wsync();
             continue;
+        }
+        wsync();                                                       // bnd[] is written
+        if (len <= KMX_PSORT_PAIR_CAP) {
+            // Up to four runs of fewer than 256 positions each (m = k - 1 on a text whose buckets hold about 100): every run
+            // gets a slot of P entries in LDS (P = the power of two above the longest run), padded with 0xFFFFFFFF — the rank
+            // of a position in its sibling run is then log2(P) branch-free halving steps from one pointer, no bounds to check
+            // (4 VALU instructions per step and position instead of 8).  Round 1 merges runs (0,1) and (2,3) into two slots of
+            // 2P entries, round 2 ranks every position in the other pair and writes it to its final place in global memory.
+            const uint32_t e1 = bnd[wv][1], e2 = R >= 2 ? bnd[wv][2] : len, e3 = R >= 3 ? bnd[wv][3] : len, e4 = len;
+            const uint32_t L0 = e1, L1 = e2 - e1, L2 = e3 - e2, L3 = e4 - e3;                     // wave-uniform
+            const uint32_t longest = max(max(L0, L1), max(L2, L3));
+            uint32_t P = 1;
+            while (P <= longest) P <<= 1;
+            if (8 * P <= KMX_PSORT_CAP) {
+                constexpr int C = KMX_PSORT_PAIR_CAP / KMX_WAVE;
+                uint32_t* __restrict__ b = buf[wv];
+                uint32_t x[C], mi[C], gi[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const uint32_t t = lane + uint32_t(c) * KMX_WAVE;
+                    gi[c] = uint32_t(t >= e1) + uint32_t(t >= e2) + uint32_t(t >= e3);              // run of t
+                    const uint32_t gs = gi[c] == 0 ? 0u : gi[c] == 1 ? e1 : gi[c] == 2 ? e2 : e3;    // its start
+                    mi[c] = t - gs;                                                                // index of t in its run
+                    x[c] = seg[min(t, len - 1)];
+                }
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (lane + uint32_t(c) * KMX_WAVE < len) b[gi[c] * P + mi[c]] = x[c];
+                for (uint32_t j = L0 + lane; j < P; j += KMX_WAVE) b[j] = 0xFFFFFFFFu;
+                for (uint32_t j = L1 + lane; j < P; j += KMX_WAVE) b[P + j] = 0xFFFFFFFFu;
+                for (uint32_t j = L2 + lane; j < P; j += KMX_WAVE) b[2 * P + j] = 0xFFFFFFFFu;
+                for (uint32_t j = L3 + lane; j < P; j += KMX_WAVE) b[3 * P + j] = 0xFFFFFFFFu;
+                wsync();
+                {
+                    const KMX_LDS uint32_t* at[C];
+                    uint32_t tv[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) at[c] = (const KMX_LDS uint32_t*)b + (gi[c] ^ 1u) * P;   // the sibling run's slot
+                    for (uint32_t st = P >> 1; st; st >>= 1) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) tv[c] = at[c][st - 1];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) at[c] += tv[c] < x[c] ? st : 0u;
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) mi[c] += uint32_t(at[c] - ((const KMX_LDS uint32_t*)b + (gi[c] ^ 1u) * P));
+                }
+                if (R <= 2) {                                            // one pair: that was the whole sort
+#pragma unroll
+                    for (int c = 0; c < C; ++c)
+                        if (lane + uint32_t(c) * KMX_WAVE < len) seg[mi[c]] = x[c];
+                    wsync();                                             // buf / bnd are reused by the next query
+                    continue;
+                }
+                uint32_t* __restrict__ b2 = b + 4 * P;                   // the two merged pairs: slots of 2P entries
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    if (lane + uint32_t(c) * KMX_WAVE < len) b2[(gi[c] >> 1) * 2 * P + mi[c]] = x[c];
+                for (uint32_t j = L0 + L1 + lane; j < 2 * P; j += KMX_WAVE) b2[j] = 0xFFFFFFFFu;
+                for (uint32_t j = L2 + L3 + lane; j < 2 * P; j += KMX_WAVE) b2[2 * P + j] = 0xFFFFFFFFu;
+                wsync();
+                {
+                    const KMX_LDS uint32_t* at[C];
+                    uint32_t tv[C];
+#pragma unroll
+                    for (int c = 0; c < C; ++c) at[c] = (const KMX_LDS uint32_t*)b2 + ((gi[c] >> 1) ^ 1u) * 2 * P;   // the other pair's slot
+                    for (uint32_t st = P; st; st >>= 1) {
+#pragma unroll
+                        for (int c = 0; c < C; ++c) tv[c] = at[c][st - 1];
+#pragma unroll
+                        for (int c = 0; c < C; ++c) at[c] += tv[c] < x[c] ? st : 0u;
+                    }
+#pragma unroll
+                    for (int c = 0; c < C; ++c) {
+                        const uint32_t rank = uint32_t(at[c] - ((const KMX_LDS uint32_t*)b2 + ((gi[c] >> 1) ^ 1u) * 2 * P));
+                        // a position of pair 1 comes after every smaller one of pair 0 and after its own pair's smaller ones
+                        if (lane + uint32_t(c) * KMX_WAVE < len) seg[mi[c] + rank] = x[c];
+                    }
+                }
+                wsync();                                                 // buf / bnd are reused by the next query
+                continue;
+            }
         }
         for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][t] = seg[t];
         wsync();
