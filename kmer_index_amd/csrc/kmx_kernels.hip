@@ -630,7 +630,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     }
     if (my_prefix) {
         const uint32_t plen = cnt - uint32_t(__popcll(aux));
-        if (c0 <= KMX_PSORT_MAX_RUNS && plen <= KMX_PSORT_CAP) {
+        if (KMX_PSORT_IS_SMALL(c0, plen)) {
             loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
         } else {
             loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
@@ -2239,11 +2239,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
         const uint32_t q = d.prefix_list[i];
         const uint32_t R = d.c0[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-        if (R > KMX_PSORT_MAX_RUNS || len > KMX_PSORT_CAP || R < 2 || len < 2) continue;   // wave-uniform
+        if (!KMX_PSORT_IS_SMALL(R, len) || R < 2 || len < 2) continue;   // wave-uniform
         const uint64_t m = qoff[q + 1] - qoff[q];
         const KmxPlanEntry pe = load_plan(ix, m);
         const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
-        if (lane <= R) bnd[wv][lane] = offs[lane] - offs[0];
+        if (lane <= min(R, uint32_t(KMX_PSORT_MAX_RUNS))) bnd[wv][lane] = offs[lane] - offs[0];
         uint32_t* __restrict__ seg = out + hit_off[q];
         auto wsync = [] {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2633,7 +2633,7 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc
         const uint32_t q = d.prefix_list[i];
         const uint32_t R = d.c0[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-        const bool small = R <= KMX_PSORT_MAX_RUNS && len <= KMX_PSORT_CAP;
+        const bool small = KMX_PSORT_IS_SMALL(R, len);
         if (small || R < 2 || len < 2) continue;                                          // block-uniform
         const uint32_t n_chunks = (len + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP;
         for (uint32_t c = blockIdx.y; c < n_chunks; c += gridDim.y) {

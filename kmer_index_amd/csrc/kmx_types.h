@@ -88,15 +88,17 @@ struct KmxIndexDev {
     KmxElemDev elems[KMX_MAX_KS];
 };
 
-// PREFIX queries whose slice has at most KMX_PSORT_MAX_RUNS per-key runs and KMX_PSORT_CAP positions are
-// sorted in LDS by one wave (k_prefix_sort_small); larger ones go through the global merge passes.
+// PREFIX queries whose slice has at most KMX_PSORT_CAP positions are sorted in LDS by one wave (k_prefix_sort_small:
+// merges by rank up to 4 runs, a bitonic sort beyond — the number of runs does not matter to that one: a protein index
+// has 20 runs of three positions behind every (k-1)-letter query); larger ones go through the global merge passes.
+#define KMX_PSORT_IS_SMALL(runs, len) ((len) <= KMX_PSORT_CAP)
 #define KMX_VRESOLVE 4          // k_lookup follows up to this many candidates of a single-k query through its parts itself
 // Bytes allocated past the last arena element.  Kernels read 16 bytes at any element (k_fill, the staging of k_validate), and
 // k_validate reads a chunk of candidates through one pointer clamped to the bucket's last entry + immediate offsets of up to
 // 7 rounds x 16 lanes x 4 bytes: both stay inside the allocation whatever the bucket.
 #define KMX_ARENA_PAD 1024
 #define KMX_VTINY 8             // k_validate_tiny: one thread per STITCH query up to this many candidates / filter entries
-#define KMX_PSORT_MAX_RUNS 16
+#define KMX_PSORT_MAX_RUNS 16   // run boundaries kept per query by k_prefix_sort_small (its merge paths need 4 of them)
 #define KMX_PSORT_CAP 2048
 // ... up to KMX_PSORT_BLOCK_CAP positions (any number of runs) by one 1024-thread block (bitonic sort in
 // 128 KB of LDS, k_prefix_sort_block); beyond that the global merge passes.
