@@ -50,10 +50,18 @@ namespace kmx {
                                            // query to validate_big_wave, which anchors it on its smallest bucket
 #define KMX_P1_DELTA_MASK 0x3FFFFFFFu      // offset of the filter part in the query (bits 32..61 of p1)
 #define KMX_VBIG 1024                      // candidates beyond which a STITCH query counts as big
+// A filter bucket of more than 256 entries does not fit the stage of a 16-lane group in k_validate; up to KMX_VWIDE entries
+// the query gets a wave of its own with the whole stage (k_validate_wide) instead of searching the bucket where it lies.
+#define KMX_VWIDE_MIN 256
+#define KMX_VWIDE 1024
 
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+__device__ __forceinline__ bool stitch_is_wide(uint64_t p1)
+{
+    return !(p1 & KMX_P1_BIG) && uint32_t(p1) > KMX_VWIDE_MIN && uint32_t(p1) <= KMX_VWIDE;
+}
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & (KMX_WAVE - 1); }
 
 // Pointers that are loaded from the index header are "generic" to the compiler, which then
@@ -623,7 +631,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         if (c0 <= KMX_VTINY && uint32_t(p1) <= KMX_VTINY) {
             loc = atomicAdd(&bc.n_stitch_tiny, 1u) | 0x80000000u;    // tiny: one thread validates it, listed from the back
         } else {
-            if (p1 & (KMX_P1_MORE | KMX_P1_BIG)) atomicAdd(&bc.n_more, 1u);
+            if ((p1 & (KMX_P1_MORE | KMX_P1_BIG)) || stitch_is_wide(p1)) atomicAdd(&bc.n_more, 1u);
             loc = atomicAdd(&bc.n_stitch, 1u);
         }
         loc_words = atomicAdd(&bc.words, my_words);
@@ -832,7 +840,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         const uint64_t src = src_raw & ~SRC_FLAGS;
         uint64_t* __restrict__ words = mask_words + wbase;
         const uint64_t sbase = wbase * 64;
-        const bool fast = have && (INLINE_MORE || !(p1 & KMX_P1_BIG));  // (big queries: validate_big_wave, from k_validate_more)
+        const bool fast = have && (INLINE_MORE || (!(p1 & KMX_P1_BIG) && !stitch_is_wide(p1)));  // (big: validate_big_wave; wide: k_validate_wide)
         const bool more = INLINE_MORE && (p1 & KMX_P1_MORE) != 0;
         const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
         const bool staged = fast && pcnt <= KMX_VSTAGE;
@@ -953,6 +961,99 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         }
         __builtin_amdgcn_wave_barrier();                                // stage[] is reused by the next round
 
+    }
+}
+
+#define KMX_VWIDE_SCAN 8
+// k_validate_wide — STITCH queries whose filter bucket has 257 ... KMX_VWIDE entries: more than a 16-lane group of k_validate
+// stages, few enough for the stage of a whole wave.  Same filter as k_validate (:283 binary_search, :544-546 lower_bound),
+// lane = candidate, 64 per round = one compressed_bitset word per ballot, eight rounds searched in lockstep.  Lane = list
+// entry while looking for such queries, then the wave takes them one by one.  Runs behind k_validate<false> and in front
+// of the kernels that check further parts (they read the survivors this one leaves).
+static_assert(KMX_VWIDE_MIN == KMX_VSTAGE, "k_validate stages filter buckets up to KMX_VSTAGE entries itself");
+__device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ arena, const QueryDesc& d, uint32_t q,
+                                                   uint64_t* __restrict__ mask_words, uint32_t* __restrict__ flat)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t c0 = d.c0[q];
+    const uint64_t src = d.src[q] & ~SRC_FLAGS;
+    const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
+    const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
+    const uint32_t P = pcnt > 512 ? 1024u : 512u;                      // pcnt in (256, 1024]; a bucket of exactly P entries is searched
+    {                                                                   // by membership only, so no pad entry is needed
+        const uint32_t last = pcnt - 1u;
+        const uint32_t* __restrict__ fil = arena + p1src;
+        for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_WAVE) {
+            const uint32_t t = t0 + 4u * lane;
+            u32x4 v = *reinterpret_cast<const u32x4_a4*>(fil + min(t, last));
+            v.x = t + 0 < pcnt ? v.x : 0xFFFFFFFFu;
+            v.y = t + 1 < pcnt ? v.y : 0xFFFFFFFFu;
+            v.z = t + 2 < pcnt ? v.z : 0xFFFFFFFFu;
+            v.w = t + 3 < pcnt ? v.w : 0xFFFFFFFFu;
+            *reinterpret_cast<u32x4*>(flat + t) = v;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint64_t* __restrict__ words = mask_words + wbase;
+    uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + wbase * 64 : nullptr;
+    const uint32_t* __restrict__ cand = arena + src;
+    const uint32_t c_last = c0 ? c0 - 1u : 0u;
+    const uint32_t n_rounds = (c0 + KMX_WAVE - 1) / KMX_WAVE;
+    const uint64_t below = (uint64_t(1) << lane) - 1;
+    uint32_t valid = 0;
+    for (uint32_t it0 = 0; it0 < n_rounds; it0 += KMX_VCH) {
+        const uint32_t nr = min(uint32_t(KMX_VCH), n_rounds - it0);
+        const uint32_t ci0 = it0 * KMX_WAVE + lane;
+        uint32_t x[KMX_VCH];
+#pragma unroll
+        for (int r = 0; r < KMX_VCH; ++r) x[r] = cand[min(ci0 + uint32_t(r) * KMX_WAVE, c_last)] + delta;   // dead slots re-read the last candidate
+        const uint32_t n_live = ci0 < c0 ? min(uint32_t(KMX_VCH), (c0 - ci0 + KMX_WAVE - 1) / KMX_WAVE) : 0u;
+        uint32_t okm;
+        switch ((nr + 1) >> 1) {
+            case 1: okm = staged_members<2>(flat, P, x); break;
+            case 2: okm = staged_members<4>(flat, P, x); break;
+            case 3: okm = staged_members<6>(flat, P, x); break;
+            default: okm = staged_members<8>(flat, P, x); break;
+        }
+        okm &= (1u << n_live) - 1u;
+#pragma unroll
+        for (int r = 0; r < KMX_VCH; ++r) {
+            if (uint32_t(r) >= nr) break;
+            const bool ok = (okm & (1u << r)) != 0;
+            const uint64_t bal = __ballot(ok);                          // 64 candidates = one bitset word (bit i = word i>>6, bit i&63)
+            if (ok && sh_out) sh_out[valid + uint32_t(__popcll(bal & below))] = x[r] - delta;
+            valid += uint32_t(__popcll(bal));
+            if (lane == 0) words[it0 + uint32_t(r)] = bal;
+        }
+    }
+    if (lane == 0) {
+        if ((c0 & 63) == 0) words[c0 / 64] = 0;                         // n_bits/64 + 1 words (compressed_bitset.hpp:23)
+        d.cnt[q] = valid;
+    }
+    __builtin_amdgcn_wave_barrier();                                    // the stage is reused by the wave's next query
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate_wide(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_stitch,
+                                                             uint64_t* __restrict__ mask_words)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VWIDE];
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    // few list entries per wave and round, so that the flagged queries spread over many waves
+    for (uint64_t i0 = wave * KMX_VWIDE_SCAN; i0 < n_stitch; i0 += n_waves * KMX_VWIDE_SCAN) {
+        const uint64_t i = i0 + lane;
+        const bool have = lane < KMX_VWIDE_SCAN && i < n_stitch;
+        const uint32_t q = have ? d.stitch_list[i] : 0u;
+        const uint64_t p1 = have ? d.p1[q] : 0;
+        uint64_t todo = __ballot(have && stitch_is_wide(p1));
+        while (todo) {
+            const int l = __ffsll((unsigned long long)todo) - 1;
+            todo &= todo - 1;
+            validate_wide_wave(arena, d, uint32_t(__shfl(int(q), l)), mask_words, stage[threadIdx.x / KMX_WAVE]);
+        }
     }
 }
 
@@ -2506,6 +2607,10 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
     }
     hipLaunchKernelGGL(k_validate<false>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
     if (n_more) {
+        // (n_more counts the queries with work behind k_validate<false>: further parts, big ones, wide filter buckets)
+        const uint64_t sw = (n_stitch + KMX_VWIDE_SCAN - 1) / KMX_VWIDE_SCAN;
+        const unsigned int sblocks = (unsigned int)std::min<uint64_t>((sw + 3) / 4, 256 * 16);
+        hipLaunchKernelGGL(k_validate_wide, dim3(sblocks ? sblocks : 1), block, 0, s, arena, d, n_stitch, mask_words);
         hipLaunchKernelGGL(k_validate_more_thread, dim3(blocks_for(n_stitch, KMX_BLOCK)), block, 0, s, ix, arena, qranks, qoff, d, n_stitch,
                            uint32_t(n_more >= KMX_VMORE_THREAD_MANY ? KMX_VMORE_THREAD_PARTS_MANY : KMX_VMORE_THREAD_PARTS), mask_words);
         hipLaunchKernelGGL(k_validate_more, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);

@@ -397,6 +397,57 @@ def test_many_reads_with_few_to_ten_parts_take_the_thread_per_query_check(engine
     idx.close()
 
 
+@pytest.mark.parametrize("ks", [[6], [6, 9]])
+def test_filter_buckets_of_a_few_hundred_entries_take_the_wide_path(engine, orc, ks):
+    """k_validate_wide: a filter bucket of 257..1024 entries does not fit the stage of a 16-lane group; the query gets a wave
+    with the whole stage.  k = 6 on 1.5e6 letters: buckets of about 366 positions; reads of 7..40 letters (rest parts, two
+    parts, further parts), planted, planted with one letter changed, random.  Oracle in full, masks against hits."""
+    import ctypes as C
+    rng = np.random.default_rng(31)
+    n, nq = 1_500_000, 6000
+    text = synth.ranks(777, n, 4)
+    lens = rng.integers(7, 41, nq)
+    starts = rng.integers(0, n - 50, nq)
+    qs = []
+    for i in range(nq):
+        q = text[starts[i]:starts[i] + lens[i]].copy()
+        kind = i % 3
+        if kind == 1:
+            j = int(rng.integers(0, lens[i]))
+            q[j] = (q[j] + 1 + int(rng.integers(0, 3))) % 4
+        elif kind == 2:
+            q = rng.integers(0, 4, lens[i]).astype(np.uint8)
+        qs.append(q)
+    qranks, qoff = pack(qs)
+    idx = engine.Index(text, 4, ks, keep_host_arena=True)
+    oidx = orc.Index(text, 4, ks)
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=8)
+    for flags in (engine.SEARCH_DEFAULT, engine.SEARCH_KEEP_MASKS, engine.SEARCH_COUNT_ONLY):
+        r = idx.search(qranks, qoff, flags=flags)
+        ho, pos, st, kd = r.host()
+        assert np.array_equal(st, o_st.astype(np.uint8)) and np.array_equal(ho, o_off)
+        if flags != engine.SEARCH_COUNT_ONLY:
+            assert np.array_equal(pos, o_pos)
+        if flags == engine.SEARCH_KEEP_MASKS:
+            base, words_ptr, cand_cnt, cand_src = r.masks()
+            arena = idx.arena_host()
+            wide = 0
+            for i in range(0, nq, 5):
+                if kd[i] != engine.KIND_STITCH:
+                    continue
+                nw = int(cand_cnt[i]) // 64 + 1
+                words = np.ctypeslib.as_array(C.cast(words_ptr, C.POINTER(C.c_uint64)), shape=(int(base[i]) + nw,))[int(base[i]):]
+                bits = np.unpackbits(words.view(np.uint8), bitorder="little")
+                assert not bits[cand_cnt[i]:nw * 64].any(), i            # the padding bits of the last word stay 0
+                bits = bits[:cand_cnt[i]].astype(bool)
+                cands = arena[int(cand_src[i]):int(cand_src[i]) + int(cand_cnt[i])]
+                assert np.array_equal(cands[bits], pos[int(ho[i]):int(ho[i + 1])]), i
+                wide += int(cand_cnt[i] > 256)
+            assert wide > 100
+        r.close()
+    idx.close()
+
+
 def test_concurrent_host_threads_share_one_index(engine, orc):
     """kmx.h: one index may be searched from several host threads at once (search() is const in the reference,
     kmer_index.hpp:505).  Host-buffer calls serialise on the index's internal stream; device-buffer calls run on
