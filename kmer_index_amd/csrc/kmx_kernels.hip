@@ -53,11 +53,18 @@ namespace kmx {
 // A filter bucket of more than 256 entries does not fit the stage of a 16-lane group in k_validate; up to KMX_VWIDE entries
 // the query gets a wave of its own with the whole stage (k_validate_wide) instead of searching the bucket where it lies.
 #define KMX_VWIDE_MIN 256
-#define KMX_VWIDE 1024
+#define KMX_VWIDE 2048
 
 // ---------------------------------------------------------------------------
 // small device helpers
 // ---------------------------------------------------------------------------
+// KMX_P1_BIG: the first part's bucket is long AND anchoring the query on its smallest bucket pays — the filter bucket is
+// much shorter than the candidates, or too long for any stage.  Two long buckets of the same order (a small k over a long
+// text: 13-letter reads on a k = 8 element, 1526 positions per bucket at 1e8 letters) are the wide path's case.
+__device__ __forceinline__ bool stitch_goes_big(uint32_t first_cnt, uint32_t filter_cnt)
+{
+    return first_cnt > KMX_VBIG && (filter_cnt > KMX_VWIDE || uint64_t(filter_cnt) * 8 < first_cnt);
+}
 __device__ __forceinline__ bool stitch_is_wide(uint64_t p1)
 {
     return !(p1 & KMX_P1_BIG) && uint32_t(p1) > KMX_VWIDE_MIN && uint32_t(p1) <= KMX_VWIDE;
@@ -362,7 +369,7 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
                             kind = KMX_KIND_STITCH; src = first.src; c0 = first.cnt;
                             key = extra.src;
                             p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (P - 1 + (rest ? 1 : 0) > 1 ? KMX_P1_MORE : 0);
-                            if (!(flags & KMX_SEARCH_KEEP_MASKS) && first.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
+                            if (!(flags & KMX_SEARCH_KEEP_MASKS) && stitch_goes_big(first.cnt, extra.cnt)) p1 |= KMX_P1_BIG;
                             if (track) {
                                 const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
                                 if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
@@ -415,7 +422,7 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
                     kind = KMX_KIND_STITCH; src = r.src; c0 = r.cnt;
                     key = extra.src;
                     p1 = (uint64_t(extra_delta) << 32) | extra.cnt | (nparts > 2 ? KMX_P1_MORE : 0);
-                    if (!(flags & KMX_SEARCH_KEEP_MASKS) && r.cnt > KMX_VBIG) p1 |= KMX_P1_BIG;
+                    if (!(flags & KMX_SEARCH_KEEP_MASKS) && stitch_goes_big(r.cnt, extra.cnt)) p1 |= KMX_P1_BIG;
                     if (track) {
                         // r is the first summand's bucket now (offset 0): which of its entries are surviving starts?
                         uint32_t fmask = 0;
@@ -979,7 +986,8 @@ __device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ 
     const uint64_t src = d.src[q] & ~SRC_FLAGS;
     const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
     const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
-    const uint32_t P = pcnt > 512 ? 1024u : 512u;                      // pcnt in (256, 1024]; a bucket of exactly P entries is searched
+    uint32_t P = 512;                                                   // pcnt in (256, KMX_VWIDE]; a bucket of exactly P entries is searched
+    while (P < pcnt) P <<= 1;
     {                                                                   // by membership only, so no pad entry is needed
         const uint32_t last = pcnt - 1u;
         const uint32_t* __restrict__ fil = arena + p1src;
@@ -1035,13 +1043,14 @@ __device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ 
     __builtin_amdgcn_wave_barrier();                                    // the stage is reused by the wave's next query
 }
 
-__global__ __launch_bounds__(KMX_BLOCK) void k_validate_wide(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_stitch,
-                                                             uint64_t* __restrict__ mask_words)
+#define KMX_VWIDE_BLOCK 256                 // four waves per block: 4 x 8 KB of stage, five blocks per CU
+__global__ __launch_bounds__(KMX_VWIDE_BLOCK) void k_validate_wide(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_stitch,
+                                                                   uint64_t* __restrict__ mask_words)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VWIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_VWIDE_BLOCK / KMX_WAVE][KMX_VWIDE];
     const uint32_t lane = lane_id();
-    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
-    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_VWIDE_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_VWIDE_BLOCK / KMX_WAVE);
     // few list entries per wave and round, so that the flagged queries spread over many waves
     for (uint64_t i0 = wave * KMX_VWIDE_SCAN; i0 < n_stitch; i0 += n_waves * KMX_VWIDE_SCAN) {
         const uint64_t i = i0 + lane;
@@ -2610,7 +2619,7 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
         // (n_more counts the queries with work behind k_validate<false>: further parts, big ones, wide filter buckets)
         const uint64_t sw = (n_stitch + KMX_VWIDE_SCAN - 1) / KMX_VWIDE_SCAN;
         const unsigned int sblocks = (unsigned int)std::min<uint64_t>((sw + 3) / 4, 256 * 16);
-        hipLaunchKernelGGL(k_validate_wide, dim3(sblocks ? sblocks : 1), block, 0, s, arena, d, n_stitch, mask_words);
+        hipLaunchKernelGGL(k_validate_wide, dim3(sblocks ? sblocks : 1), dim3(KMX_VWIDE_BLOCK), 0, s, arena, d, n_stitch, mask_words);
         hipLaunchKernelGGL(k_validate_more_thread, dim3(blocks_for(n_stitch, KMX_BLOCK)), block, 0, s, ix, arena, qranks, qoff, d, n_stitch,
                            uint32_t(n_more >= KMX_VMORE_THREAD_MANY ? KMX_VMORE_THREAD_PARTS_MANY : KMX_VMORE_THREAD_PARTS), mask_words);
         hipLaunchKernelGGL(k_validate_more, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);

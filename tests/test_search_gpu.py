@@ -397,11 +397,12 @@ def test_many_reads_with_few_to_ten_parts_take_the_thread_per_query_check(engine
     idx.close()
 
 
-@pytest.mark.parametrize("ks", [[6], [6, 9]])
+@pytest.mark.parametrize("ks", [[6], [6, 9], [5]])
 def test_filter_buckets_of_a_few_hundred_entries_take_the_wide_path(engine, orc, ks):
-    """k_validate_wide: a filter bucket of 257..1024 entries does not fit the stage of a 16-lane group; the query gets a wave
-    with the whole stage.  k = 6 on 1.5e6 letters: buckets of about 366 positions; reads of 7..40 letters (rest parts, two
-    parts, further parts), planted, planted with one letter changed, random.  Oracle in full, masks against hits."""
+    """k_validate_wide: a filter bucket of 257..2048 entries does not fit the stage of a 16-lane group; the query gets a wave
+    with a stage of its own.  k = 6 on 1.5e6 letters: buckets of about 366 positions; k = 5: about 1465 (more candidates than
+    KMX_VBIG, but a filter bucket of the same order: not a case for anchoring on the smallest bucket); reads of 7..40 letters
+    (rest parts, two parts, further parts), planted, planted with one letter changed, random.  Oracle in full, masks against hits."""
     import ctypes as C
     rng = np.random.default_rng(31)
     n, nq = 1_500_000, 6000

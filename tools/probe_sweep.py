@@ -22,6 +22,8 @@ INDEXES = [
     ("aa27 k=4,6", 27, 5_000_000, [4, 6]),
     ("binary k=20", 2, 5_000_000, [20]),
 ]
+if os.environ.get("KMX_SWEEP_N"):          # the same indexes over a longer text (buckets grow with it)
+    INDEXES = [(a, b, int(os.environ["KMX_SWEEP_N"]), d) for a, b, c, d in INDEXES]
 only = sys.argv[1:]
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
@@ -32,6 +34,8 @@ for name, sigma, n, ks in INDEXES:
     idx = engine.Index(text, sigma, ks)
     k = ks[-1]
     lens = sorted({max(1, ks[0] - 2), ks[0] - 1, ks[0], k, k + 1, k + 3, 2 * k, 2 * k + 3, 3 * k + 1, 5 * k + 2, 64, 200})
+    if os.environ.get("KMX_SWEEP_LENS"):
+        lens = [int(v) for v in os.environ["KMX_SWEEP_LENS"].split(",")]
     for m in lens:
         nq = 500_000 if m <= 64 else 200_000
         q, off = synth.mixed_queries(100 + m, text, nq, [m], sigma)
