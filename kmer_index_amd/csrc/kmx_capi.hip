@@ -109,12 +109,12 @@ struct HostBuf {
 };
 
 enum KernelId {
-    K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS, K_COPY_BACK,
-    K_PREFIX_SORT_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_COUNT
+    K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS,
+    K_PREFIX_SORT_SMALL, K_PREFIX_MERGE_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_lookup", "k_scan", "k_partition", "k_fill", "k_validate", "k_compact",
-    "k_prefix_len", "k_merge_pass", "k_prefix_copy_back", "k_prefix_sort_small", "k_prefix_sort_block", "k_small"};
+    "k_prefix_len", "k_prefix_merge_pass", "k_prefix_sort_small", "k_prefix_merge_small", "k_prefix_sort_block", "k_small"};
 
 struct Stats {
     bool enabled = false;
@@ -416,6 +416,11 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         }
         ix->allocs.push_back(p);
         ix->device_bytes += arena_elems * 4;
+        // the padding reads as 0xFFFFFFFF, k_fill's "do not store" (kmx_types.h, KMX_ARENA_PAD)
+        {
+            hipError_t e = hipMemset(static_cast<unsigned char*>(p) + arena_elems * 4, 0xFF, KMX_ARENA_PAD);
+            if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("arena padding: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+        }
         h.arena = static_cast<const uint32_t*>(p);
         ix->d_arena = h.arena;
     }
@@ -1313,36 +1318,39 @@ static kmx_status search_finish(kmx_result* r)
     // PREFIX work list: small queries from the front of prefix_list, the others from its back
     kmx::QueryDesc d_big = d;
     d_big.prefix_list = d.prefix_list + (nq - n_prefix_big);
-    if (n_prefix_small)
-        timed(ix, K_PREFIX_SORT_SMALL, s, [&] { kmx::launch_prefix_sort_small(s, dix, qo, d, n_prefix_small, hit_off, out); });
-    if (n_prefix_big)
-        timed(ix, K_PREFIX_SORT_BLOCK, s, [&] { kmx::launch_prefix_sort_block(s, d_big, n_prefix_big, hit_off, out); });
-
-    if (n_prefix_big && max_runs > 1 && prefix_elems > 0) {
-        // slices beyond the block sort's capacity: their 32 K chunks are sorted by now, merge the chunks
-        const uint64_t np = n_prefix_big;
-        HIP_TRY(r->plen.ensure(np * 4));
-        HIP_TRY(r->poff.ensure((np + 1) * 8));
-        HIP_TRY(r->ptmp.ensure(prefix_elems * 4));
-        HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(np), kmx::scan_blocks(nq)) * 8));
-        timed(ix, K_PREFIX_LEN, s, [&] { kmx::launch_prefix_len(s, d_big, np, r->plen.as<uint32_t>()); });
-        timed(ix, K_SCAN, s, [&] {
-            kmx::launch_scan(s, r->plen.as<uint32_t>(), np, r->bsum.as<uint64_t>(), r->poff.as<uint64_t>(), ctr + KMX_CTR_PREFIX_TOTAL);
-        });
-        uint32_t passes = 0;
-        while ((uint64_t(1) << passes) < max_runs) ++passes;
-        int src_is_out = 1;
-        for (uint32_t p = 0; p < passes; ++p) {
-            timed(ix, K_MERGE_PASS, s, [&] {
-                kmx::launch_merge_pass(s, d_big, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out,
-                                       r->ptmp.as<uint32_t>(), p, src_is_out);
+    const uint64_t n_prefix_merge = r->h_ctr[KMX_CTR_PREFIX_MERGE];       // of the small ones: k_prefix_merge_small's class
+    if (n_prefix_small > n_prefix_merge)
+        timed(ix, K_PREFIX_SORT_SMALL, s, [&] { kmx::launch_prefix_sort_small(s, dix, qo, d, n_prefix_small, hit_off, ix->d_arena, out); });
+    if (n_prefix_merge)
+        timed(ix, K_PREFIX_MERGE_SMALL, s, [&] { kmx::launch_prefix_merge_small(s, dix, qo, d, n_prefix_small, hit_off, ix->d_arena, out); });
+    if (n_prefix_big) {
+        // slices beyond the block kernel's capacity are rows of sorted chunks behind it, merged pairwise in global memory:
+        // their tiles are counted first (the chunks of a slice with an odd number of passes start in the scratch buffer)
+        const bool large = max_runs > 1 && prefix_elems > 0;
+        const uint64_t np = n_prefix_big, T = kmx::prefix_merge_tile();
+        const uint64_t max_tiles = large ? prefix_elems / T + np : 0;
+        if (large) {
+            HIP_TRY(r->plen.ensure(np * 4));
+            HIP_TRY(r->poff.ensure((np + 1) * 8));
+            HIP_TRY(r->ptmp.ensure(max_tiles * T * 4));
+            HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(np), kmx::scan_blocks(nq)) * 8));
+            timed(ix, K_PREFIX_LEN, s, [&] { kmx::launch_prefix_len(s, d_big, np, r->plen.as<uint32_t>()); });
+            timed(ix, K_SCAN, s, [&] {
+                kmx::launch_scan(s, r->plen.as<uint32_t>(), np, r->bsum.as<uint64_t>(), r->poff.as<uint64_t>(), ctr + KMX_CTR_PREFIX_TOTAL);
             });
-            src_is_out = !src_is_out;
         }
-        if (!src_is_out)
-            timed(ix, K_COPY_BACK, s, [&] {
-                kmx::launch_prefix_copy_back(s, d_big, np, r->poff.as<uint64_t>(), prefix_elems, hit_off, out, r->ptmp.as<uint32_t>());
-            });
+        timed(ix, K_PREFIX_SORT_BLOCK, s, [&] {
+            kmx::launch_prefix_sort_block(s, dix, qo, d_big, np, hit_off, ix->d_arena, out, large ? r->poff.as<uint64_t>() : nullptr,
+                                          large ? r->ptmp.as<uint32_t>() : nullptr);
+        });
+        if (large) {
+            uint32_t passes = 0;
+            while ((uint64_t(1) << passes) < max_runs) ++passes;
+            for (uint32_t p = 0; p < passes; ++p)
+                timed(ix, K_MERGE_PASS, s, [&] {
+                    kmx::launch_prefix_merge_pass(s, d_big, np, r->poff.as<uint64_t>(), max_tiles, hit_off, out, r->ptmp.as<uint32_t>(), p);
+                });
+        }
     }
     HIP_TRY(hipGetLastError());
     return KMX_OK;

@@ -91,12 +91,17 @@ void launch_build_phase2(hipStream_t s, const uint8_t* d_text, uint64_t n, uint3
                          unsigned int* d_info, unsigned long long* d_total, uint32_t* d_region, uint32_t* d_aoffs, uint32_t a0,
                          int sort_mode, uint32_t* d_atab, uint32_t region_end);
 void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_keys, uint32_t* d_positions);
+// the PREFIX queries with a short slice (front of prefix_list): two kernels, each takes its class and skips the other's
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
-                              const uint64_t* hit_off, uint32_t* out);
-void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off, uint32_t* out);
-void launch_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
-                       const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass, int src_is_out);
-void launch_prefix_copy_back(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff,
-                             uint64_t p_total, const uint64_t* hit_off, uint32_t* out, const uint32_t* tmp);
+                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out);
+void launch_prefix_merge_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out);
+// tile_off / tmp: only when the batch has slices beyond KMX_PSORT_BLOCK_CAP (launch_prefix_len + a scan give tile_off)
+void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp);
+// one pairwise merge pass over the sorted chunks of the large slices; max_tiles >= tile_off[n_prefix]
+void launch_prefix_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* tile_off, uint64_t max_tiles,
+                              const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass);
+uint64_t prefix_merge_tile();
 
 } // namespace kmx

@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <type_traits>
 
 #include "kmx_kernels.h"
 
@@ -34,6 +35,14 @@
 #ifndef KMX_PSORT_MULTIWAY_RUNS
 #define KMX_PSORT_MULTIWAY_RUNS 4   // k_prefix_sort_small: multi-way rank pass up to this many runs, bitonic beyond
 #endif
+// merge_runs_lds: steps per thread and LDS slack of the wave-level (k_prefix_merge_small) and the block-level user
+#define KMX_PM_WAVE_EMAX ((KMX_PSORT_CAP + (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2) - 1) / (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2))   // 43
+#define KMX_PM_WAVE_PAD (KMX_PSORT_MAX_RUNS + KMX_PM_WAVE_EMAX + 5)   // sentinel cells + the reads of a chunk past its end
+// k_prefix_sort_block: chunks of up to KMX_PM_BLOCK_RUNS runs are merged the same way by 1024 threads
+#define KMX_PM_BLOCK_RUNS 128
+#define KMX_PM_BLOCK_EMAX ((KMX_PSORT_BLOCK_CAP + (1024 - KMX_PM_BLOCK_RUNS / 2) - 1) / (1024 - KMX_PM_BLOCK_RUNS / 2))       // 35
+#define KMX_PM_BLOCK_PAD (KMX_PM_BLOCK_RUNS + KMX_PM_BLOCK_EMAX + 5)
+#define KMX_PM_TILE 4096     // k_prefix_merge_pass: output positions per workgroup (divides KMX_PSORT_BLOCK_CAP)
 #define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
 
 namespace kmx {
@@ -450,7 +459,7 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_stitch_tiny, n_resolved, n_prefix, n_prefix_big, n_error, n_none, n_more;
+    unsigned int n_stitch, n_stitch_tiny, n_resolved, n_prefix, n_prefix_big, n_prefix_merge, n_error, n_none, n_more;
     unsigned long long words, pelems, hits;
     unsigned int max_runs;
     unsigned int base_stitch, base_stitch_tiny, base_prefix, base_prefix_big;
@@ -468,7 +477,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_stitch_tiny = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_error = bc.n_none = bc.n_more = 0;
+        bc.n_stitch = bc.n_stitch_tiny = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_prefix_merge = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = bc.hits = 0;
         bc.max_runs = 0;
     }
@@ -647,6 +656,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         const uint32_t plen = cnt - uint32_t(__popcll(aux));
         if (KMX_PSORT_IS_SMALL(c0, plen)) {
             loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
+            if (KMX_PSORT_IS_MERGE(c0, plen)) atomicAdd(&bc.n_prefix_merge, 1u);
         } else {
             loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
             if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: chunks sorted in LDS, then merged in global memory
@@ -691,6 +701,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             if (bc.n_more) atomicAdd(&ctr[KMX_CTR_STITCH_MORE], (unsigned long long)bc.n_more);
         }
         if (bc.n_prefix) bc.base_prefix = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX], (unsigned long long)bc.n_prefix);
+        if (bc.n_prefix_merge) atomicAdd(&ctr[KMX_CTR_PREFIX_MERGE], (unsigned long long)bc.n_prefix_merge);
         if (bc.n_prefix_big) {
             bc.base_prefix_big = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX_BIG], (unsigned long long)bc.n_prefix_big);
             if (bc.pelems) atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
@@ -2131,11 +2142,15 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
             } else if (sv & SRC_PREFIX) {
                 // [s, s + len): the contiguous slice of every k-mer with this prefix -> plain copy;
                 // [s + len, e): last-kmer positions (kmer_index.hpp:90-112) -> per-slot path
+                // A slice of two or more runs is read, put in order and written by the prefix sort / merge kernels: its slots
+                // here read the arena's padding, which says "do not store" (0xFFFFFFFF, KMX_ARENA_PAD).
                 const uint64_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
                 const uint64_t mid = s + len;
                 if (len && mid > base) {
                     const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
-                    word[slot] = rec_t((sv & ~SRC_FLAGS) + (base + slot - s) + (TILE - slot));
+                    const bool sorted_elsewhere = len >= 2 && d.c0[q] >= 2;
+                    word[slot] = sorted_elsewhere ? rec_t(ix->arena_elems + (TILE - slot))
+                                                  : rec_t((sv & ~SRC_FLAGS) + (base + slot - s) + (TILE - slot));
                 }
                 if (e > mid && mid < tile_end) {
                     const uint32_t slot = mid > base ? uint32_t(mid - base) : 0u;
@@ -2220,7 +2235,7 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
     if constexpr (sizeof(rec_t) == 4) {
         // buffer_load with a 32-bit voffset against a wave-uniform descriptor: one address VGPR per load
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint32_t*>(arena), 0, int(uint32_t(ix->arena_elems * 4 + 64)), 0x00020000);
+            const_cast<uint32_t*>(arena), 0, int(uint32_t(ix->arena_elems * 4 + KMX_ARENA_PAD)), 0x00020000);
 #pragma unroll
         for (int j = 0; j < E; ++j) {
             const uint32_t slot = j * KMX_BLOCK + tid;
@@ -2311,6 +2326,154 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_compact(const uint32_t* __restric
 }
 
 // ---------------------------------------------------------------------------
+// merge_runs_lds — the std::sort of kmer_index_result.hpp:258 for a slice that is the concatenation of R ASCENDING runs
+// (the buckets of consecutive keys, kmer_index.hpp:131-144): ceil(log2 R) rounds of pairwise merges in LDS, every round
+// O(len) work — a merge, not a sort of unordered data.
+//
+// NT threads share one slice in `buf`.  A round merges the groups (2p, 2p+1) for every pair p: the pair's output is cut
+// into chunks of E consecutive positions, one chunk per thread (sum over pairs of ceil(len_p / E) <= NT by the choice of
+// E); a thread finds where its chunk starts in both groups (merge path: one binary search along the chunk's diagonal)
+// and then merges E steps sequentially into registers; behind a barrier the registers go back to the buffer.  From the
+// second round on the groups lie in a GAPPED layout — group g of the round at [bnd[g*w] + g, ...) with one cell holding
+// 0xFFFFFFFF (never a position: n + k - 1 < 2^32, kmer_index.hpp:169-170) behind its last entry — so that a step needs
+// no bounds: compare, min, advance one of two indices, one LDS read.  The first round reads the slice as it was staged
+// (no gaps) and checks its indices instead.  An unpaired last group is merged with an empty one (= moved).
+// buf: len + R + EMAX + 2 words at least; bnd: R + 1 run boundaries (bnd[0] = 0, bnd[R] = len); ptab: 4 * (pairs + 1)
+// words.  R <= 2 * 64 pairs, and E = ceil(len / (NT - pairs)) <= EMAX is the caller's business.  On return (behind a
+// sync) buf[0, len) is ascending.  tools/model_prefix_merge.py is a host model of the index arithmetic.
+// ---------------------------------------------------------------------------
+#define KMX_PM_SENT 0xFFFFFFFFu
+// E sequential merge steps from the heads *pa / *pb into x[0, E).  A step: compare the heads, keep the smaller, advance that
+// side, read its next entry — 8 VALU instructions and one LDS read when the groups end in sentinel cells; CHECKED (a slice as
+// it was staged, no sentinels): the entry read at or behind a group's end counts as the sentinel (+3).
+template <int EMAX, bool CHECKED>
+__device__ __forceinline__ void merge_chunk(const KMX_LDS uint32_t* pa, const KMX_LDS uint32_t* pb, const KMX_LDS uint32_t* a_end,
+                                            const KMX_LDS uint32_t* b_end, uint32_t E, uint32_t (&x)[EMAX])
+{
+    uint32_t va = *pa, vb = *pb;
+    if (CHECKED) {
+        va = pa < a_end ? va : KMX_PM_SENT;
+        vb = pb < b_end ? vb : KMX_PM_SENT;
+    }
+#pragma unroll
+    for (int j = 0; j < EMAX; ++j) {
+        if (uint32_t(j) < E) {                                    // uniform over the cooperating threads
+            const bool c = va < vb;
+            x[j] = c ? va : vb;
+            const KMX_LDS uint32_t* t = (c ? pa : pb) + 1;
+            uint32_t nv = *t;
+            if (CHECKED) nv = t < (c ? a_end : b_end) ? nv : KMX_PM_SENT;
+            pa = c ? t : pa;
+            pb = c ? pb : t;
+            va = c ? nv : va;
+            vb = c ? vb : nv;
+        }
+    }
+}
+
+// Where diagonal dg of the merge of A[0, na) and B[0, nb) crosses the merge path: the a in [max(0, dg - nb), min(dg, na)]
+// with A[0, a) and B[0, dg - a) the dg smallest.  `steps` halving steps from a bracket of 2^steps - 1 (>= min(na, nb, dg) for
+// every cooperating thread), branch-free: a candidate beyond the bracket reads a clamped entry and is refused.
+__device__ __forceinline__ uint32_t merge_path_cut_lds(const KMX_LDS uint32_t* A, uint32_t na, const KMX_LDS uint32_t* B, uint32_t nb,
+                                                       uint32_t dg, uint32_t steps)
+{
+    uint32_t lo = dg > nb ? dg - nb : 0u;
+    const uint32_t hi = min(dg, na);
+    const KMX_LDS uint32_t* Bd = B + dg;
+    for (uint32_t st = steps ? 1u << (steps - 1) : 0u; st; st >>= 1) {
+        const uint32_t cand = lo + st, cc = min(cand, hi);        // A[cand - 1] < B[dg - cand]: cand is not past the crossing
+        const bool ok = (cand <= hi) & (A[int32_t(cc) - 1] < Bd[-int32_t(cc)]);
+        lo = ok ? cand : lo;
+    }
+    return lo;
+}
+
+// E = ceil(len / (NT - ceil(R / 2))), rcp = floor(2^32 / E) + 1 (division by E as a multiplication: exact below 2^32 / E).
+template <int EMAX, int NT, typename Sync>
+__device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R, uint32_t len,
+                                               uint32_t E, uint32_t rcp, uint32_t tid, Sync sync)
+{
+    KMX_LDS uint32_t* lb = (KMX_LDS uint32_t*)buf;
+    const KMX_LDS uint32_t* lbnd = (const KMX_LDS uint32_t*)bnd;
+    KMX_LDS uint32_t* lpt = (KMX_LDS uint32_t*)ptab;
+    const uint32_t lane = tid & (KMX_WAVE - 1);
+    uint32_t w = 1, ngroups = R;
+    bool first = true;
+    while (ngroups > 1) {
+        const uint32_t npairs = (ngroups + 1) >> 1;
+        if (tid < KMX_WAVE) {                                     // the pair table: {start, middle, end, first chunk}
+            uint32_t s = 0, mi = 0, e = 0, nch = 0;
+            if (tid < npairs) {
+                const uint32_t g0 = 2 * tid;
+                s = lbnd[min(g0 * w, R)];
+                mi = lbnd[min((g0 + 1) * w, R)];
+                e = lbnd[min((g0 + 2) * w, R)];
+                nch = __umulhi(e - s + E - 1, rcp);
+                if (!first && e == mi) lb[mi + 2 * tid + 1] = KMX_PM_SENT;      // the empty partner of an unpaired group
+            }
+            uint32_t inc = nch, longest = min(mi - s, e - mi);
+#pragma unroll
+            for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if (lane >= o) inc += t;
+                longest = max(longest, uint32_t(__shfl_xor(longest, o)));
+            }
+            if (tid < npairs) {
+                lpt[4 * tid] = s;
+                lpt[4 * tid + 1] = mi;
+                lpt[4 * tid + 2] = e;
+                lpt[4 * tid + 3] = inc - nch;
+            }
+            if (tid == npairs - 1) lpt[4 * npairs + 3] = inc;     // chunks in all
+            if (tid == 0) lpt[4 * npairs + 2] = longest;          // the longest "shorter side" of any pair: bounds every bracket
+        }
+        sync();
+        const uint32_t total = lpt[4 * npairs + 3];
+        uint32_t steps = 0;
+        {
+            const uint32_t longest = __builtin_amdgcn_readfirstlane(lpt[4 * npairs + 2]);
+            while ((1u << steps) <= longest) ++steps;
+        }
+        const bool active = tid < total;
+        uint32_t p = 0;
+        {
+            uint32_t step = 1;
+            while (step < npairs) step <<= 1;
+            for (step >>= 1; step; step >>= 1) {
+                const uint32_t cnd = p + step;
+                if (cnd < npairs && lpt[4 * cnd + 3] <= tid) p = cnd;
+            }
+        }
+        const uint32_t s = lpt[4 * p], mi = lpt[4 * p + 1], e = lpt[4 * p + 2], ch0 = lpt[4 * p + 3];
+        const uint32_t na = active ? mi - s : 0u, nb = active ? e - mi : 0u;
+        const uint32_t dg = active ? (tid - ch0) * E : 0u;         // the chunk's diagonal
+        const uint32_t nout = active ? min(E, na + nb - dg) : 0u;
+        const KMX_LDS uint32_t* pA = lb + (first ? s : s + 2 * p);
+        const KMX_LDS uint32_t* pB = lb + (first ? mi : mi + 2 * p + 1);
+        const uint32_t lo = merge_path_cut_lds(pA, na, pB, nb, dg, steps);
+        // (the two kinds of round as two copies of "merge, barrier, write back": one set of registers each)
+        auto round = [&](auto checked) {
+            uint32_t x[EMAX];
+            merge_chunk<EMAX, decltype(checked)::value>(pA + lo, pB + (dg - lo), lb + mi, lb + e, E, x);
+            sync();                                                // every read of the round is done
+            KMX_LDS uint32_t* o = lb + (s + p + dg);
+#pragma unroll
+            for (int j = 0; j < EMAX; ++j)
+                if (uint32_t(j) < E) {
+                    if (uint32_t(j) < nout) o[j] = x[j];
+                }
+        };
+        if (first) round(std::true_type{});
+        else round(std::false_type{});
+        if (tid < npairs) lb[lpt[4 * tid + 2] + tid] = KMX_PM_SENT;   // the cell behind every merged group
+        sync();
+        w <<= 1;
+        ngroups = npairs;
+        first = false;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // k_merge_pass — PREFIX queries: the slice copied by k_fill is the concatenation
 // of the ascending runs of consecutive keys; pass t merges neighbouring groups
 // of 2^t runs by ranking every element in its sibling group (no two runs share a
@@ -2327,17 +2490,22 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t 
     if (i >= n_prefix) return;
     const uint32_t q = d.prefix_list[i];   // (the launcher passes the list region it wants walked)
     const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-    plen[i] = len > KMX_PSORT_BLOCK_CAP ? len : 0u;   // the others: k_prefix_sort_small / k_prefix_sort_block
+    // large slices: output tiles of k_prefix_merge_pass (the scan of these is both the tile table and, times the tile, the
+    // slice's place in the scratch buffer); the others are finished by k_prefix_sort_small / k_prefix_sort_block
+    // (a slice of ONE run is in order as k_fill copies it: no chunks, no passes)
+    plen[i] = (len > KMX_PSORT_BLOCK_CAP && d.c0[q] >= 2) ? (len + KMX_PM_TILE - 1) / KMX_PM_TILE : 0u;
 }
 
-// PREFIX queries with few runs and a short slice: one wave sorts the slice that k_fill copied.  The
-// slice is the concatenation of R <= 16 ascending runs (one per key of the prefix range); a position's
-// final rank is the sum over the runs of "how many of this run are smaller" — one multi-way pass of
-// binary searches in LDS, which is the std::sort of kmer_index_result.hpp:258 for this query.
+// PREFIX queries with a short slice (<= KMX_PSORT_CAP positions), one wave per query.  The slice is the concatenation of
+// R ascending runs (one per key of the prefix range) and is read where it lies in the arena (k_fill leaves the slots of
+// a slice with two or more runs alone); what leaves for `out` is ascending — the std::sort of kmer_index_result.hpp:258.
+// This kernel: up to four runs / 512 positions (what m = k - 1 yields on DNA) from registers, by rank in the sibling
+// run; slices of many short runs by a bitonic network.  The class in between is k_prefix_merge_small's.
 __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexDev* __restrict__ ix,
                                                                  const uint64_t* __restrict__ qoff, QueryDesc d,
                                                                  uint64_t n_prefix,
                                                                  const uint64_t* __restrict__ hit_off,
+                                                                 const uint32_t* __restrict__ arena,
                                                                  uint32_t* __restrict__ out)
 {
     __shared__ uint32_t buf[KMX_BLOCK / KMX_WAVE][KMX_PSORT_CAP];
@@ -2349,7 +2517,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
         const uint32_t q = d.prefix_list[i];
         const uint32_t R = d.c0[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-        if (!KMX_PSORT_IS_SMALL(R, len) || R < 2 || len < 2) continue;   // wave-uniform
+        if (!KMX_PSORT_IS_SMALL(R, len) || KMX_PSORT_IS_MERGE(R, len) || R < 2 || len < 2) continue;   // wave-uniform
+        const uint32_t* __restrict__ srcp = arena + (d.src[q] & ~SRC_FLAGS);
         const uint64_t m = qoff[q + 1] - qoff[q];
         const KmxPlanEntry pe = load_plan(ix, m);
         const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
@@ -2361,11 +2530,10 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         };
         if (R > KMX_PSORT_MULTIWAY_RUNS) {
-            // many runs: a bitonic sort of the staged slice (independent compare-exchanges per stage) beats
-            // R - 1 dependent binary searches per position
+            // many short runs: a bitonic sort of the staged slice (independent compare-exchanges per stage)
             uint32_t n2 = 2;
             while (n2 < len) n2 <<= 1;
-            for (uint32_t t = lane; t < n2; t += KMX_WAVE) buf[wv][t] = t < len ? seg[t] : 0xFFFFFFFFu;
+            for (uint32_t t = lane; t < n2; t += KMX_WAVE) buf[wv][t] = t < len ? srcp[t] : 0xFFFFFFFFu;
             wsync();
             bitonic_lds(buf[wv], n2, lane, uint32_t(KMX_WAVE), wsync);
             for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][t];
@@ -2394,7 +2562,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
                     gi[c] = uint32_t(t >= e1) + uint32_t(t >= e2) + uint32_t(t >= e3);              // run of t
                     const uint32_t gs = gi[c] == 0 ? 0u : gi[c] == 1 ? e1 : gi[c] == 2 ? e2 : e3;    // its start
                     mi[c] = t - gs;                                                                // index of t in its run
-                    x[c] = seg[min(t, len - 1)];
+                    x[c] = srcp[min(t, len - 1)];
                 }
 #pragma unroll
                 for (int c = 0; c < C; ++c)
@@ -2454,7 +2622,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
                 continue;
             }
         }
-        for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][t] = seg[t];
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][t] = srcp[t];
         wsync();
         if (len <= KMX_PSORT_PAIR_CAP) {
             // Up to four runs, every lane holds its (at most KMX_PSORT_PAIR_CAP / 64) positions in registers: the runs are
@@ -2521,48 +2689,136 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
     }
 }
 
-__global__ __launch_bounds__(KMX_BLOCK) void k_merge_pass(QueryDesc d, uint64_t n_prefix,
-                                                          const uint64_t* __restrict__ poff, uint64_t p_total,
-                                                          const uint64_t* __restrict__ hit_off,
-                                                          uint32_t* __restrict__ out, uint32_t* __restrict__ tmp,
-                                                          uint32_t pass, int src_is_out)
+// The small PREFIX slices in between: 2 .. KMX_PSORT_MAX_RUNS runs that average KMX_PMERGE_MIN_AVG positions or more (m = k - 2
+// on DNA: 16 runs, 1526 positions at 1e8 letters) — merged, ceil(log2 R) rounds in LDS (merge_runs_lds), one wave per query.
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_small(const KmxIndexDev* __restrict__ ix,
+                                                                  const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                                  uint64_t n_prefix,
+                                                                  const uint64_t* __restrict__ hit_off,
+                                                                  const uint32_t* __restrict__ arena,
+                                                                  uint32_t* __restrict__ out)
 {
-    // The slice of a large PREFIX query is a row of KMX_PSORT_BLOCK_CAP-position chunks, each already sorted by
-    // k_prefix_sort_block; pass t merges neighbouring groups of 2^t chunks by ranking every position in its
-    // sibling group (positions are distinct, so ranks are unique).
-    const uint64_t e = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
-    if (e >= p_total) return;
-    const uint64_t i = upper_bound_dev<uint64_t>(poff, n_prefix + 1, e) - 1;
-    const uint32_t q = d.prefix_list[i];
-    const uint64_t idx = e - poff[i];
-    const uint64_t len = poff[i + 1] - poff[i];
-    const uint32_t* __restrict__ in = src_is_out ? out + hit_off[q] : tmp + poff[i];
-    uint32_t* __restrict__ ot = src_is_out ? tmp + poff[i] : out + hit_off[q];
-    const uint64_t CH = KMX_PSORT_BLOCK_CAP;
-    const uint64_t n_runs = (len + CH - 1) / CH;
-    const uint32_t x = in[idx];
-    const uint64_t g = (idx / CH) >> pass;
-    const uint64_t sib_first = (g ^ 1) << pass;
-    if (sib_first >= n_runs) { ot[idx] = x; return; }          // no sibling group: carried over
-    const uint64_t own_lo = (g << pass) * CH;
-    const uint64_t sib_lo = sib_first * CH;
-    const uint64_t sib_hi = min(len, (sib_first + (uint64_t(1) << pass)) * CH);
-    const uint64_t rank = lower_bound_dev<uint32_t>(in + sib_lo, sib_hi - sib_lo, x);
-    ot[min(own_lo, sib_lo) + (idx - own_lo) + rank] = x;
+    __shared__ uint32_t buf[KMX_BLOCK / KMX_WAVE][KMX_PSORT_CAP + KMX_PM_WAVE_PAD];
+    __shared__ uint32_t bnd[KMX_BLOCK / KMX_WAVE][KMX_PSORT_MAX_RUNS + 1];
+    __shared__ uint32_t ptab[KMX_BLOCK / KMX_WAVE][4 * (KMX_PSORT_MAX_RUNS / 2 + 1)];
+    const uint32_t lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    for (uint64_t i = wave; i < n_prefix; i += n_waves) {
+        // (everything about the query is the same in every lane: say so, the merge steps branch on it)
+        const uint32_t q = __builtin_amdgcn_readfirstlane(d.prefix_list[i]);
+        const uint32_t R = __builtin_amdgcn_readfirstlane(d.c0[q]);
+        const uint32_t len = __builtin_amdgcn_readfirstlane(d.cnt[q] - uint32_t(__popcll(d.aux[q])));
+        if (!KMX_PSORT_IS_MERGE(R, len)) continue;
+        const uint32_t* __restrict__ srcp = arena + (d.src[q] & ~SRC_FLAGS);
+        const KmxPlanEntry pe = load_plan(ix, qoff[q + 1] - qoff[q]);
+        const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
+        if (lane <= R) bnd[wv][lane] = offs[lane] - offs[0];
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][1 + t] = srcp[t];
+        const uint32_t E = max(2u, (len + (KMX_WAVE - (R + 1) / 2) - 1) / (KMX_WAVE - (R + 1) / 2));
+        const uint32_t rcp = 0xFFFFFFFFu / E + 1;
+        wsync();
+        merge_runs_lds<KMX_PM_WAVE_EMAX, KMX_WAVE>(buf[wv] + 1, bnd[wv], ptab[wv], R, len, E, rcp, lane, wsync);
+        uint32_t* __restrict__ seg = out + hit_off[q];
+        for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][1 + t];
+        wsync();                                                               // buf / bnd / ptab are the next query's
+    }
 }
 
-__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_copy_back(QueryDesc d, uint64_t n_prefix,
-                                                                const uint64_t* __restrict__ poff,
-                                                                uint64_t p_total,
-                                                                const uint64_t* __restrict__ hit_off,
-                                                                uint32_t* __restrict__ out,
-                                                                const uint32_t* __restrict__ tmp)
+// passes a slice of n_chunks sorted chunks needs until it is one ascending list
+__device__ __forceinline__ uint32_t prefix_merge_passes(uint32_t len)
 {
-    const uint64_t e = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
-    if (e >= p_total) return;
-    const uint64_t i = upper_bound_dev<uint64_t>(poff, n_prefix + 1, e) - 1;
+    const uint32_t n_chunks = (len + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP;
+    uint32_t p = 0;
+    while ((1u << p) < n_chunks) ++p;
+    return p;
+}
+
+// first index a in [max(0, dg - nb), min(dg, na)] with !(A[a] < B[dg - 1 - a]): where diagonal dg of the merge of A and B
+// crosses the merge path (A[0, a) and B[0, dg - a) are the dg smallest)
+template <typename PA, typename PB>
+__device__ __forceinline__ uint32_t merge_path_cut(PA A, uint32_t na, PB B, uint32_t nb, uint32_t dg)
+{
+    uint32_t lo = dg > nb ? dg - nb : 0u, hi = min(dg, na);
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] < B[dg - 1 - mid]) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// The slice of a large PREFIX query is a row of KMX_PSORT_BLOCK_CAP-position chunks, each ascending after
+// k_prefix_sort_block; pass t merges neighbouring groups of 2^t chunks — a merge of two ascending lists, O(len) per pass:
+// a workgroup owns KMX_PM_TILE consecutive output positions (tiles never straddle a pair: pairs start at multiples of the
+// chunk size), cuts both groups where the tile's two diagonals cross the merge path (two binary searches in global
+// memory), stages the two pieces in LDS and merges them there, 16 outputs per thread, leaving coalesced.
+// Buffers alternate between `out` (slice of query q at hit_off[q]) and `tmp` (at tile_off[i] * KMX_PM_TILE); a query with
+// P passes starts in the buffer that makes its LAST pass land in `out` (k_prefix_sort_block writes there), so there is
+// no copy back, and a query is not touched by passes beyond its own.
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_pass(QueryDesc d, uint64_t n_prefix,
+                                                                 const uint64_t* __restrict__ tile_off,
+                                                                 const uint64_t* __restrict__ hit_off,
+                                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ tmp,
+                                                                 uint32_t pass)
+{
+    constexpr uint32_t T = KMX_PM_TILE, E = KMX_PM_TILE / KMX_BLOCK;
+    __shared__ uint32_t buf[T + 2 + E];
+    __shared__ uint32_t cut[2];
+    const uint64_t b = blockIdx.x;
+    if (b >= tile_off[n_prefix]) return;
+    const uint64_t i = upper_bound_dev<uint64_t>(tile_off, n_prefix + 1, b) - 1;
     const uint32_t q = d.prefix_list[i];
-    out[hit_off[q] + (e - poff[i])] = tmp[e];
+    const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    const uint32_t P = prefix_merge_passes(len);
+    if (pass >= P) return;
+    const bool dst_is_out = ((P - pass) & 1u) != 0;
+    uint32_t* __restrict__ s_out = out + hit_off[q];
+    uint32_t* __restrict__ s_tmp = tmp + tile_off[i] * T;
+    const uint32_t* __restrict__ src = dst_is_out ? s_tmp : s_out;
+    uint32_t* __restrict__ dst = dst_is_out ? s_out : s_tmp;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t G = uint64_t(KMX_PSORT_BLOCK_CAP) << pass;                   // positions per group
+    const uint64_t o0 = (b - tile_off[i]) * T;                                  // first output of the tile, in the slice
+    const uint64_t a_lo = (o0 / (2 * G)) * (2 * G);
+    const uint64_t a_hi = min(a_lo + G, uint64_t(len)), b_hi = min(a_hi + G, uint64_t(len));
+    const uint32_t na = uint32_t(a_hi - a_lo), nb = uint32_t(b_hi - a_hi);
+    const uint32_t d0 = uint32_t(o0 - a_lo), d1 = min(d0 + T, na + nb);
+    const uint32_t n_out = d1 - d0;
+    if (nb == 0) {                                                               // no sibling group: carried over
+        for (uint32_t t = tid; t < n_out; t += KMX_BLOCK) dst[o0 + t] = src[o0 + t];
+        return;
+    }
+    const uint32_t* __restrict__ A = src + a_lo;
+    const uint32_t* __restrict__ B = src + a_hi;
+    if (tid == 0) cut[0] = merge_path_cut(A, na, B, nb, d0);
+    if (tid == KMX_WAVE) cut[1] = merge_path_cut(A, na, B, nb, d1);
+    __syncthreads();
+    const uint32_t a0 = cut[0], a1 = cut[1], b0 = d0 - a0;
+    const uint32_t nA = a1 - a0, nB = n_out - nA;
+    // A's piece at [0, nA), a sentinel, B's piece at [nA + 1, nA + 1 + nB), a sentinel
+    for (uint32_t t = tid; t < n_out + 2; t += KMX_BLOCK) {
+        uint32_t v = KMX_PM_SENT;
+        if (t < nA) v = A[a0 + t];
+        else if (t > nA && t < n_out + 1) v = B[b0 + (t - nA - 1)];
+        buf[t] = v;
+    }
+    __syncthreads();
+    const KMX_LDS uint32_t* lb = (const KMX_LDS uint32_t*)buf;
+    const uint32_t dg = min(tid * E, n_out);
+    const uint32_t lo = merge_path_cut(lb, nA, lb + (nA + 1), nB, dg);
+    uint32_t x[E];
+    merge_chunk<int(E), false>(lb + lo, lb + (nA + 1 + dg - lo), nullptr, nullptr, E, x);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t j = 0; j < E; ++j)
+        if (dg + j < n_out) buf[dg + j] = x[j];
+    __syncthreads();
+    for (uint32_t t = tid; t < n_out; t += KMX_BLOCK) dst[o0 + t] = buf[t];
 }
 
 // ---------------------------------------------------------------------------
@@ -2733,15 +2989,25 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 }
 
 
-// PREFIX slices that are too long or have too many runs for k_prefix_sort_small but fit 128 KB of
-// LDS: one 1024-thread block per query, bitonic sort of the slice padded to a power of two.
+// PREFIX slices beyond k_prefix_sort_small's capacity: one 1024-thread block per chunk of up to KMX_PSORT_BLOCK_CAP
+// positions (a slice up to that length is one chunk and done after this; longer ones: k_prefix_merge_pass).  The
+// chunk is a row of ascending runs — the runs of the slice, cut at the chunk's ends — whose boundaries the block takes
+// from the element's offset table: up to KMX_PM_BLOCK_RUNS of them are merged (merge_runs_lds), more are sorted by the
+// bitonic network as before.
 #define KMX_PSB_THREADS 1024
-__global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc d, uint64_t n_prefix,
+__global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
+                                                                        const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                                        uint64_t n_prefix,
                                                                         const uint64_t* __restrict__ hit_off,
-                                                                        uint32_t* __restrict__ out)
+                                                                        const uint32_t* __restrict__ arena,
+                                                                        uint32_t* __restrict__ out,
+                                                                        const uint64_t* __restrict__ tile_off,
+                                                                        uint32_t* __restrict__ tmp)
 {
-    // mid-size slices whole; slices beyond the capacity chunk by chunk (k_merge_pass merges the chunks afterwards)
-    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // KMX_PSORT_BLOCK_CAP + KMX_PM_BLOCK_PAD words
+    __shared__ uint32_t bnd[KMX_PM_BLOCK_RUNS + 1];
+    __shared__ uint32_t ptab[4 * (KMX_PM_BLOCK_RUNS / 2 + 1)];
+    __shared__ uint32_t runs[2];
     const uint32_t tid = threadIdx.x;
     for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
         const uint32_t q = d.prefix_list[i];
@@ -2750,28 +3016,55 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(QueryDesc
         const bool small = KMX_PSORT_IS_SMALL(R, len);
         if (small || R < 2 || len < 2) continue;                                          // block-uniform
         const uint32_t n_chunks = (len + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP;
+        // where the chunks go: `out`, or the scratch buffer when the slice needs an odd number of merge passes
+        uint32_t* __restrict__ sorted = (prefix_merge_passes(len) & 1u) ? tmp + tile_off[i] * KMX_PM_TILE : out + hit_off[q];
+        const KmxPlanEntry pe = load_plan(ix, qoff[q + 1] - qoff[q]);
+        const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];   // R + 1 run boundaries
+        const uint32_t offs0 = offs[0];
         for (uint32_t c = blockIdx.y; c < n_chunks; c += gridDim.y) {
             const uint32_t c_lo = c * KMX_PSORT_BLOCK_CAP;
             const uint32_t c_len = min(uint32_t(KMX_PSORT_BLOCK_CAP), len - c_lo);
+            const uint32_t* __restrict__ seg = arena + (d.src[q] & ~SRC_FLAGS) + c_lo;    // where the slice lies
+            if (tid == 0) {
+                // the run that holds the chunk's first position, the first boundary at or behind its end
+                const uint32_t r0 = uint32_t(upper_bound_dev<uint32_t>(offs, uint64_t(R) + 1, offs0 + c_lo)) - 1;
+                const uint32_t r1 = uint32_t(lower_bound_dev<uint32_t>(offs, uint64_t(R) + 1, offs0 + c_lo + c_len));
+                runs[0] = r0;
+                runs[1] = r1 - r0;
+            }
+            __syncthreads();
+            const uint32_t r0 = __builtin_amdgcn_readfirstlane(runs[0]), Rc = __builtin_amdgcn_readfirstlane(runs[1]);
+            const bool merge = Rc <= KMX_PM_BLOCK_RUNS;
+            if (merge && tid <= Rc) {
+                const uint32_t o = offs[r0 + tid] - offs0;
+                bnd[tid] = o <= c_lo ? 0u : min(o - c_lo, c_len);
+            }
             uint32_t n2 = 2;
             while (n2 < c_len) n2 <<= 1;
-            uint32_t* __restrict__ seg = out + hit_off[q] + c_lo;
-            for (uint32_t t = tid; t < n2; t += KMX_PSB_THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
+            const uint32_t n_stage = merge ? c_len : n2;
+            for (uint32_t t = tid; t < n_stage; t += KMX_PSB_THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
             __syncthreads();
-            bitonic_lds(sbuf, n2, tid, uint32_t(KMX_PSB_THREADS), [] { __syncthreads(); });
-            for (uint32_t t = tid; t < c_len; t += KMX_PSB_THREADS) seg[t] = sbuf[t];
+            if (merge) {
+                const uint32_t E = max(2u, (c_len + (KMX_PSB_THREADS - (Rc + 1) / 2) - 1) / (KMX_PSB_THREADS - (Rc + 1) / 2));
+                merge_runs_lds<KMX_PM_BLOCK_EMAX, KMX_PSB_THREADS>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+            }
+            else bitonic_lds(sbuf, n2, tid, uint32_t(KMX_PSB_THREADS), [] { __syncthreads(); });
+            uint32_t* __restrict__ dst = sorted + c_lo;
+            for (uint32_t t = tid; t < c_len; t += KMX_PSB_THREADS) dst[t] = sbuf[t];
             __syncthreads();
         }
     }
 }
 
-void launch_prefix_sort_block(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off, uint32_t* out)
+void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp)
 {
-    const size_t lds = size_t(KMX_PSORT_BLOCK_CAP) * 4;
+    const size_t lds = size_t(KMX_PSORT_BLOCK_CAP + KMX_PM_BLOCK_PAD) * 4;
     allow_big_lds(reinterpret_cast<const void*>(k_prefix_sort_block), lds, 0);
     unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
     const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks
-    hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(KMX_PSB_THREADS), lds, s, d, n_prefix, hit_off, out);
+    hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(KMX_PSB_THREADS), lds, s, ix, qoff, d,
+                       n_prefix, hit_off, arena, out, tile_off, tmp);
 }
 
 // ---------------------------------------------------------------------------
@@ -3010,24 +3303,26 @@ void launch_bucket_sort_block(hipStream_t s, const uint32_t* d_offs, uint64_t n_
 }
 
 void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
-                              const uint64_t* hit_off, uint32_t* out)
+                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out)
 {
     unsigned int blocks = (unsigned int)std::min<uint64_t>((n_prefix + 3) / 4, 256 * 32);
-    hipLaunchKernelGGL(k_prefix_sort_small, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, out);
+    hipLaunchKernelGGL(k_prefix_sort_small, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, arena, out);
 }
 
-void launch_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff, uint64_t p_total,
-                       const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass, int src_is_out)
+void launch_prefix_merge_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out)
 {
-    hipLaunchKernelGGL(k_merge_pass, dim3(blocks_for(p_total, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, poff, p_total,
-                       hit_off, out, tmp, pass, src_is_out);
+    unsigned int blocks = (unsigned int)std::min<uint64_t>((n_prefix + 3) / 4, 256 * 32);
+    hipLaunchKernelGGL(k_prefix_merge_small, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, arena, out);
 }
 
-void launch_prefix_copy_back(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* poff,
-                             uint64_t p_total, const uint64_t* hit_off, uint32_t* out, const uint32_t* tmp)
+void launch_prefix_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* tile_off, uint64_t max_tiles,
+                              const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass)
 {
-    hipLaunchKernelGGL(k_prefix_copy_back, dim3(blocks_for(p_total, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, poff,
-                       p_total, hit_off, out, tmp);
+    hipLaunchKernelGGL(k_prefix_merge_pass, dim3((unsigned int)std::max<uint64_t>(max_tiles, 1)), dim3(KMX_BLOCK), 0, s, d, n_prefix, tile_off,
+                       hit_off, out, tmp, pass);
 }
+
+uint64_t prefix_merge_tile() { return KMX_PM_TILE; }
 
 } // namespace kmx

@@ -92,13 +92,29 @@ struct KmxIndexDev {
 // merges by rank up to 4 runs, a bitonic sort beyond — the number of runs does not matter to that one: a protein index
 // has 20 runs of three positions behind every (k-1)-letter query); larger ones go through the global merge passes.
 #define KMX_PSORT_IS_SMALL(runs, len) ((len) <= KMX_PSORT_CAP)
+// ... of those, the slices merged by k_prefix_merge_small: more than the register paths of k_prefix_sort_small take (four runs,
+// 512 positions), at most KMX_PSORT_MAX_RUNS runs, and runs long enough on average to be worth a round's bookkeeping
+#ifndef KMX_PMERGE_MIN_AVG
+#define KMX_PMERGE_MIN_AVG 8
+#endif
+#define KMX_PSORT_IS_MERGE(runs, len)                                                                                   \
+    ((len) <= KMX_PSORT_CAP && (runs) >= 2 && (runs) <= KMX_PSORT_MAX_RUNS && !((runs) <= KMX_PMERGE_REG_RUNS && (len) <= KMX_PMERGE_REG_LEN) && \
+     (len) >= KMX_PMERGE_MIN_AVG * (runs))
+#ifndef KMX_PMERGE_REG_RUNS
+#define KMX_PMERGE_REG_RUNS 4
+#endif
+#ifndef KMX_PMERGE_REG_LEN
+#define KMX_PMERGE_REG_LEN 512
+#endif
 #define KMX_VRESOLVE 4          // k_lookup follows up to this many candidates of a single-k query through its parts itself
 // Bytes allocated past the last arena element.  Kernels read 16 bytes at any element (k_fill, the staging of k_validate), and
 // k_validate reads a chunk of candidates through one pointer clamped to the bucket's last entry + immediate offsets of up to
 // 7 rounds x 16 lanes x 4 bytes: both stay inside the allocation whatever the bucket.
-#define KMX_ARENA_PAD 1024
+// ... and k_fill sends the slots it must not write (a PREFIX slice the sort kernels produce themselves) to read the padding,
+// which holds 0xFFFFFFFF ("do not store") for a whole tile of slots: 4096 words + the 1024 bytes above.
+#define KMX_ARENA_PAD (4096 * 4 + 1024)
 #define KMX_VTINY 8             // k_validate_tiny: one thread per STITCH query up to this many candidates / filter entries
-#define KMX_PSORT_MAX_RUNS 16   // run boundaries kept per query by k_prefix_sort_small (its merge paths need 4 of them)
+#define KMX_PSORT_MAX_RUNS 32   // run boundaries kept per query by k_prefix_sort_small (its merge paths need 4 of them)
 #define KMX_PSORT_CAP 2048
 // ... up to KMX_PSORT_BLOCK_CAP positions (any number of runs) by one 1024-thread block (bitonic sort in
 // 128 KB of LDS, k_prefix_sort_block); beyond that the global merge passes.
@@ -172,5 +188,6 @@ enum {
     KMX_CTR_PREFIX_BIG = 11,  // PREFIX queries that are not 'small' (listed from the BACK of prefix_list)
     KMX_CTR_STITCH_TINY = 12, // STITCH queries with at most KMX_VTINY candidates and filter-bucket entries (listed from the BACK of stitch_list)
     KMX_CTR_STITCH_RESOLVED = 13, // STITCH queries k_lookup resolved by itself (tiny first bucket, survivors one run of it)
+    KMX_CTR_PREFIX_MERGE = 14, // small PREFIX queries of the merge class (KMX_PSORT_IS_MERGE): k_prefix_merge_small has work
     KMX_CTR_COUNT = 16
 };

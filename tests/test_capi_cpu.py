@@ -36,7 +36,7 @@ def test_library_carries_gfx950_code_objects():
     assert b"amdgcn-amd-amdhsa--gfx950" in data
     for arch in (b"gfx90a", b"gfx942", b"sm_"):
         assert b"amdgcn-amd-amdhsa--" + arch not in data
-    for kern in (b"k_lookup", b"k_fill", b"k_validate", b"k_compact", b"k_merge_pass", b"k_scan_down", b"k_partition"):
+    for kern in (b"k_lookup", b"k_fill", b"k_validate", b"k_compact", b"k_prefix_merge_pass", b"k_scan_down", b"k_partition"):
         assert kern in data
 
 

@@ -584,7 +584,28 @@ def test_prefix_sort_all_size_classes(engine, orc):
     assert (kd == engine.KIND_PREFIX).all()
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
     k = idx.stats()
-    assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_merge_pass"]["launches"]
+    assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_merge_small"]["launches"]
+    assert k["k_prefix_sort_block"]["launches"] and k["k_prefix_merge_pass"]["launches"]
+
+
+def test_prefix_slices_of_one_long_run_and_of_lopsided_runs(engine, orc):
+    """A periodic text: a sub-k query is answered by ONE run of tens of thousands of positions (in order as it lies — no
+    sort kernel, no merge pass may touch it), or, where the period was broken, by one long run plus runs of a single
+    position before or behind it; two interleaved phases give runs that alternate element by element."""
+    unit = np.array([0, 1, 2], np.uint8)
+    text = np.tile(unit, 40_000)
+    text[77_001] = 3                                   # a broken period: one-position runs next to the long ones
+    text[5] = 3
+    for ks in ([12], [9]):
+        idx = engine.Index(text, 4, ks, table=engine.TABLE_OPEN)
+        oidx = orc.Index(text, 4, ks)
+        qs = [text[s0:s0 + m].copy() for m in (1, 2, 3, 5, 8) for s0 in (0, 1, 2, 30, 76_995, 77_000, text.size - 8)]
+        qranks, qoff = pack(qs)
+        ho, pos, st, kd = idx.search(qranks, qoff).host()
+        o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+        assert (kd == engine.KIND_PREFIX).all()
+        assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+        idx.close()
 
 
 @pytest.mark.parametrize("sigma,ks", [(4, [16]), (4, [14, 20, 31]), (2, [40, 63]), (20, [7, 12]), (5, [12, 4])])

@@ -24,7 +24,7 @@ INDEXES = [
 ]
 if os.environ.get("KMX_SWEEP_N"):          # the same indexes over a longer text (buckets grow with it)
     INDEXES = [(a, b, int(os.environ["KMX_SWEEP_N"]), d) for a, b, c, d in INDEXES]
-only = sys.argv[1:]
+only = sys.argv[1:] or [v for v in os.environ.get("KMX_SWEEP_ONLY", "").split(";") if v]   # (the variable: names with blanks under rocprofv3)
 dev = torch.device("cuda", 0)
 stream = torch.cuda.current_stream().cuda_stream
 for name, sigma, n, ks in INDEXES:

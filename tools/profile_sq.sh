@@ -10,6 +10,9 @@ mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 -L > "$out/counters_available.txt" 2>&1
 BENCH="bench.py --config $cfg --no-cpu-baseline --no-open-compare --no-two-streams --steps 4 --warmup 1"
+# any other python command instead of the bench (a probe; its name goes where the config number would):
+#   KMX_SQ_CMD="tools/probe_sweep.py dna4_k=10" bash tools/profile_sq.sh <tag> <name>
+if [ -n "$KMX_SQ_CMD" ]; then BENCH="$KMX_SQ_CMD"; fi
 timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_BUSY_CYCLES SQ_WAVES -d "$out/pass1" -o p1 --output-format csv -- python3 $BENCH > "$out/pass1.log" 2>&1
 echo "pass1 rc=$?"
 timeout -k 10 300 rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_VMEM_RD -d "$out/pass2" -o p2 --output-format csv -- python3 $BENCH > "$out/pass2.log" 2>&1
