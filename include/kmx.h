@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KMX_VERSION 2
+#define KMX_VERSION 3
 #define KMX_MAX_KS 32               /* number of k values one index may hold                      */
 #define KMX_MAX_DEVICES 16          /* replicas of one index (one per GPU of a node)              */
 #define KMX_QUERY_SIZE_RANGE 10000  /* kmer_index::_query_size_range, kmer_index.hpp:401          */
@@ -97,6 +97,15 @@ typedef struct kmx_options {
                                   kmer::make_kmer_index uses every GPU of the node without a code change.  An ordinal may be
                                   listed more than once (replicas then share a device: only useful for testing).           */
     int32_t devices[KMX_MAX_DEVICES];
+    /* ---- since KMX_VERSION 3 ---- */
+    int32_t prefix_levels;     /* Sub-k queries (m < k, get_position_for_all_kmer_with_prefix kmer_index.hpp:115-148 + the std::sort
+                                  of kmer_index_result.hpp:258): per dense element, up to this many PREFIX LEVELS are derived when
+                                  the index is installed — level L holds, for every (k-L)-mer, the merged ascending list of all its
+                                  occurrences, so a query of k-L letters copies one list instead of merging sigma^L buckets per
+                                  query, and shorter ones merge sigma^L times fewer lists.  Results are identical; each level costs
+                                  one more copy of the position array (4 bytes x text length) and is left out when it does not
+                                  fit.  0 = default (KMX_PREFIX_LEVELS in the environment, else 2), -1 = none, N = at most N
+                                  (<= 3).  Levels are derived data: not part of the on-disk image, rebuilt by kmx_index_load. */
 } kmx_options;
 
 /* kmx_search_batch flags */

@@ -501,7 +501,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
                 (void)hipGetLastError();                            // no directory: the searches run over the whole key array
             }
         }
-        el.cnt8 = nullptr; el.cell_base = 0; el.cell_shift = 0; el.reserved0 = 0;
+        el.cnt8 = nullptr; el.cell_base = 0; el.cell_shift = 0; el.n_levels = 0;
         if (cell_shift[i]) {
             void* p = nullptr;
             hipError_t ce = hipMalloc(&p, im.n_keys + 64);                 // + 64: the lookup reads the aligned 16 bytes around an entry
@@ -613,6 +613,100 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
     return KMX_OK;
 }
 
+// Prefix levels (KmxElemDev::n_levels, kmx_options::prefix_levels) of a freshly installed index: for every dense element and
+// L = 1, 2, ... as long as the planner sends queries of k - L letters to that element, the batch of ALL (k - L)-mers is searched
+// by the engine itself (level L is merged from level L - 1: sigma lists per query) and its hit_off / positions move behind the
+// arena as the level's table and lists — one more copy of the n positions per level, bought for sub-k queries that copy one
+// list instead of merging sigma^L buckets.  Optional by nature: a level that does not fit (device memory, 32-bit arena
+// offsets, a key space too large to enumerate) is left out and so are the levels behind it.
+static kmx_status search_finish(kmx_result* r);
+static kmx_status add_prefix_levels(kmx_index* ix, const kmx_options& o)
+{
+    int want = o.prefix_levels;
+    if (want == 0) {
+        want = KMX_DEFAULT_PREFIX_LEVELS;
+        if (const char* env = getenv("KMX_PREFIX_LEVELS")) want = atoi(env);
+    }
+    if (want <= 0) return KMX_OK;
+    want = std::min(want, int(KMX_MAX_LEVELS));
+    HIP_TRY(hipSetDevice(ix->device));
+    const std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, ix->range);
+    auto up32w = [](uint64_t v) { return (v + 31) & ~uint64_t(31); };
+    for (uint32_t e = 0; e < ix->h_header.n_ks; ++e) {
+        for (int L = 1; L <= want; ++L) {
+            KmxIndexDev& h = ix->h_header;
+            KmxElemDev& el = h.elems[e];
+            if (el.table_kind != KMX_TABLE_DENSE || uint32_t(L) >= el.k) break;
+            const uint32_t m = el.k - uint32_t(L);
+            if (m >= ix->range || plan[m].scheme != KMX_SCHEME_SINGLE || plan[m].elem != e) break;   // another element answers m
+            const uint64_t nq = h.pw[m];                               // sigma^m lists
+            const uint64_t n_pos = h.n - m + 1;                        // every position starts exactly one m-mer
+            if (nq > (uint64_t(1) << 26) || nq * m > (uint64_t(1) << 30)) break;
+            const uint64_t offs_at = up32w(h.arena_elems), base = up32w(offs_at + nq + 1), new_elems = base + n_pos;
+            if ((new_elems + 65536) * 4 >= (uint64_t(1) << 32)) break;                 // 32-bit arena offsets (k_fill's records)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+            // the batch's result (positions + descriptors), the queries and the grown arena next to the old one
+            if (double(free_b) < 1.25 * double(new_elems * 4 + n_pos * 4 + nq * (m + 96)) + double(size_t(256) << 20)) break;
+            void *d_q = nullptr, *d_off = nullptr, *grown = nullptr;
+            kmx_result* r = nullptr;
+            auto cleanup = [&] {
+                if (d_q) (void)hipFree(d_q);
+                if (d_off) (void)hipFree(d_off);
+                if (grown) (void)hipFree(grown);
+                if (r) kmx_result_free(r);
+            };
+            auto soft_fail = [&] { (void)hipGetLastError(); cleanup(); };             // the level is optional
+            if (hipMalloc(&d_q, nq * m + 64) != hipSuccess || hipMalloc(&d_off, (nq + 1) * 8) != hipSuccess) { soft_fail(); break; }
+            kmx::launch_all_kmers(nullptr, m, h.sigma, nq, static_cast<uint8_t*>(d_q), static_cast<uint64_t*>(d_off));
+            if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { soft_fail(); break; }
+            kmx_status st = kmx_search_batch_device(ix, d_q, d_off, nq, KMX_SEARCH_DEFAULT, nullptr, &r);
+            if (st == KMX_ERR_OUT_OF_MEMORY) { soft_fail(); break; }
+            if (st != KMX_OK) { cleanup(); return st; }
+            if (r->n_hits != n_pos || r->n_error) {
+                cleanup();
+                return fail(KMX_ERR_HIP, "prefix level: the lists of all " + std::to_string(m) + "-mers do not add up to the text's positions");
+            }
+            if (hipMalloc(&grown, new_elems * 4 + KMX_ARENA_PAD) != hipSuccess) { soft_fail(); break; }
+            uint32_t* g = static_cast<uint32_t*>(grown);
+            hipError_t he = hipMemcpy(g, h.arena, h.arena_elems * 4, hipMemcpyDeviceToDevice);
+            if (he == hipSuccess) he = hipMemset(g + h.arena_elems, 0, (base - h.arena_elems) * 4);
+            if (he == hipSuccess) {
+                kmx::launch_narrow_offsets(nullptr, r->hit_off.as<uint64_t>(), nq + 1, g + offs_at);
+                he = hipGetLastError();
+            }
+            if (he == hipSuccess) he = hipMemcpy(g + base, r->out.as<uint32_t>(), n_pos * 4, hipMemcpyDeviceToDevice);
+            if (he == hipSuccess) he = hipMemset(g + new_elems, 0xFF, KMX_ARENA_PAD);
+            if (he == hipSuccess) he = hipDeviceSynchronize();
+            if (he != hipSuccess) { std::string msg = hipGetErrorString(he); cleanup(); return fail(KMX_ERR_HIP, "prefix level: " + msg); }
+            kmx_result_free(r); r = nullptr;
+            // swap the arenas and publish the level
+            void* old = const_cast<uint32_t*>(h.arena);
+            ix->allocs.erase(std::remove(ix->allocs.begin(), ix->allocs.end(), old), ix->allocs.end());
+            ix->allocs.push_back(grown);
+            ix->device_bytes += (new_elems - h.arena_elems) * 4;
+            h.arena = g; ix->d_arena = g;
+            h.arena_elems = new_elems;
+            el.lvl_offs_at[L - 1] = offs_at;
+            el.lvl_base[L - 1] = base;
+            el.n_levels = uint32_t(L);
+            grown = nullptr;
+            he = hipMemcpy(ix->d_index, &h, sizeof h, hipMemcpyHostToDevice);
+            if (he == hipSuccess) he = hipDeviceSynchronize();
+            (void)hipFree(old);
+            cleanup();
+            if (he != hipSuccess) return fail(KMX_ERR_HIP, std::string("prefix level header: ") + hipGetErrorString(he));
+        }
+    }
+    // the results the level searches parked in the pool hold device memory of the size of the index: give it back
+    {
+        std::vector<kmx_result*> idle;
+        { std::lock_guard<std::mutex> lock(ix->pool->mu); idle.swap(ix->pool->idle); }
+        for (kmx_result* r : idle) { r->release(); delete r; }
+    }
+    return KMX_OK;
+}
+
 // Resolves the replica set an options struct (or the KMX_DEVICES environment variable) asks for and clones the freshly
 // built / loaded primary onto the other devices.  Leaves the caller's current device as it found it.
 static kmx_status add_replicas(kmx_index* ix, const kmx_options& o)
@@ -665,8 +759,8 @@ static bool read_options(const kmx_options* opts, kmx_options& o)
     o.struct_size = sizeof(kmx_options);
     o.device = -1;
     if (!opts) return true;
-    const size_t v1 = offsetof(kmx_options, n_devices);
-    if (opts->struct_size != sizeof(kmx_options) && opts->struct_size != v1) return false;
+    const size_t v1 = offsetof(kmx_options, n_devices), v2 = offsetof(kmx_options, prefix_levels);
+    if (opts->struct_size != sizeof(kmx_options) && opts->struct_size != v1 && opts->struct_size != v2) return false;
     memcpy(&o, opts, opts->struct_size);
     o.struct_size = sizeof(kmx_options);
     if (opts->struct_size == v1) o.n_devices = 1;          // a version-1 caller: one replica, no environment override
@@ -962,7 +1056,8 @@ kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, con
 
     st = install_images_impl(images, ranks + (n - kmax), n, sigma, range, device, o, out, arena, arena_elems);
     if (st != KMX_OK) return st;
-    st = add_replicas(*out, o);
+    st = add_prefix_levels(*out, o);
+    if (st == KMX_OK) st = add_replicas(*out, o);
     if (st != KMX_OK) { std::string keep = g_err; kmx_index_free(*out); *out = nullptr; g_err = keep; }
     return st;
 }
@@ -1128,7 +1223,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
 
     kmx_result* r = *inout;
     if (r && !r->parts.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: the result handle belongs to a multi-device search");
-    if (r && r->nq && r->device != ix->device && r->device_bytes())
+    if (r && r->device != ix->device && r->device_bytes())      // (whatever its last batch was: an empty one still owns buffers there)
         return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: the result handle holds buffers on another device");
     if (!r) { r = take_result(ix); *inout = r; }
     else if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }   // its buffers are about to be reused
@@ -1261,7 +1356,7 @@ static kmx_status search_finish(kmx_result* r)
     r->n_stitch = n_stitch_pending + r->h_ctr[KMX_CTR_STITCH_RESOLVED];                                  // (k_lookup resolved the others itself)
     r->last_had_stitch = n_stitch_pending != 0;
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
-    r->n_prefix = n_prefix_small + n_prefix_big;
+    r->n_prefix = n_prefix_small + n_prefix_big + r->h_ctr[KMX_CTR_PREFIX_PLAIN];
     r->n_error = r->h_ctr[KMX_CTR_ERROR];
     r->n_none = r->h_ctr[KMX_CTR_NONE];
     r->n_mask_words = r->h_ctr[KMX_CTR_MASK_WORDS];
@@ -1340,7 +1435,7 @@ static kmx_status search_finish(kmx_result* r)
             });
         }
         timed(ix, K_PREFIX_SORT_BLOCK, s, [&] {
-            kmx::launch_prefix_sort_block(s, dix, qo, d_big, np, hit_off, ix->d_arena, out, large ? r->poff.as<uint64_t>() : nullptr,
+            kmx::launch_prefix_sort_block(s, dix, qo, d_big, np, r->h_ctr[KMX_CTR_PREFIX_MID], hit_off, ix->d_arena, out, large ? r->poff.as<uint64_t>() : nullptr,
                                           large ? r->ptmp.as<uint32_t>() : nullptr);
         });
         if (large) {
@@ -2096,7 +2191,8 @@ extern "C" kmx_status kmx_index_load(const char* path, const kmx_options* opts, 
     HIP_TRY(hipSetDevice(device));
     st = install_images_impl(images, tail.data(), fh.n, fh.sigma, o.query_size_range ? o.query_size_range : fh.range, device, o, out, nullptr);
     if (st != KMX_OK) return st;
-    st = add_replicas(*out, o);
+    st = add_prefix_levels(*out, o);
+    if (st == KMX_OK) st = add_replicas(*out, o);
     if (st != KMX_OK) { std::string keep = g_err; kmx_index_free(*out); *out = nullptr; g_err = keep; }
     return st;
 }

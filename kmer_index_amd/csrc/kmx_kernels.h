@@ -97,11 +97,15 @@ void launch_prefix_sort_small(hipStream_t s, const KmxIndexDev* ix, const uint64
 void launch_prefix_merge_small(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
                                const uint64_t* hit_off, const uint32_t* arena, uint32_t* out);
 // tile_off / tmp: only when the batch has slices beyond KMX_PSORT_BLOCK_CAP (launch_prefix_len + a scan give tile_off)
-void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+// n_mid: how many of the listed slices have at most KMX_PSORT_MID_CAP positions (they take the 256-thread shape of the kernel)
+void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp);
 // one pairwise merge pass over the sorted chunks of the large slices; max_tiles >= tile_off[n_prefix]
 void launch_prefix_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* tile_off, uint64_t max_tiles,
                               const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass);
 uint64_t prefix_merge_tile();
+// prefix levels: the batch of all m-mers in rank-hash order (m * nq letters, nq + 1 offsets); 64-bit offsets as a 32-bit table
+void launch_all_kmers(hipStream_t s, uint32_t m, uint32_t sigma, uint64_t nq, uint8_t* d_qranks, uint64_t* d_qoff);
+void launch_narrow_offsets(hipStream_t s, const uint64_t* d_in, uint64_t n, uint32_t* d_out);
 
 } // namespace kmx

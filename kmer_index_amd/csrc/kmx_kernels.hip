@@ -38,10 +38,6 @@
 // merge_runs_lds: steps per thread and LDS slack of the wave-level (k_prefix_merge_small) and the block-level user
 #define KMX_PM_WAVE_EMAX ((KMX_PSORT_CAP + (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2) - 1) / (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2))   // 43
 #define KMX_PM_WAVE_PAD (KMX_PSORT_MAX_RUNS + KMX_PM_WAVE_EMAX + 5)   // sentinel cells + the reads of a chunk past its end
-// k_prefix_sort_block: chunks of up to KMX_PM_BLOCK_RUNS runs are merged the same way by 1024 threads
-#define KMX_PM_BLOCK_RUNS 128
-#define KMX_PM_BLOCK_EMAX ((KMX_PSORT_BLOCK_CAP + (1024 - KMX_PM_BLOCK_RUNS / 2) - 1) / (1024 - KMX_PM_BLOCK_RUNS / 2))       // 35
-#define KMX_PM_BLOCK_PAD (KMX_PM_BLOCK_RUNS + KMX_PM_BLOCK_EMAX + 5)
 #define KMX_PM_TILE 4096     // k_prefix_merge_pass: output positions per workgroup (divides KMX_PSORT_BLOCK_CAP)
 #define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
 
@@ -180,6 +176,16 @@ __device__ __forceinline__ uint64_t upper_bound_dev(P a, uint64_t n, T x)
     return lo;
 }
 
+// The run boundaries of a PREFIX query of m letters whose first key is `key` (QueryDesc::key): c0 + 1 entries of the offset
+// table lookup_query took the slice from — the element's, or its prefix level's.
+__device__ __forceinline__ const KMX_GLOBAL uint32_t* prefix_run_bounds(const KmxIndexDev* __restrict__ ix, uint64_t m, uint64_t key)
+{
+    const KmxPlanEntry pe = load_plan(ix, m);
+    const KmxElemDev* el = &ix->elems[pe.elem];
+    const uint32_t L = min(uint32_t(el->k - m), el->n_levels);
+    return (L ? as_global(ix->arena) + el->lvl_offs_at[L - 1] : as_global(el->offs)) + key;
+}
+
 // rank-hash of `len` letters by Horner's rule; equals sum r_i * sigma^(len-i-1)
 // (kmer_index.hpp:56-73) because k < 64/log2(sigma) rules out wrap-around.
 // Returns false when a letter is not a valid rank.
@@ -294,16 +300,26 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
                     if (r.cnt) { kind = KMX_KIND_EXACT; src = r.src; cnt = r.cnt; }
                 }
             } else if (m < k) {                           // :342-345 -> :115-148
-                const uint64_t R = ix->pw[k - m];         // fast_pow(sigma, k - size)
-                if (R > KMX_SUBK_FANOUT_LIMIT) {
+                if (ix->pw[k - m] > KMX_SUBK_FANOUT_LIMIT) {   // fast_pow(sigma, k - size)
                     status = KMX_Q_SUBK_FANOUT;           // :119-122
                 } else {
                     uint64_t hp;
                     ranks_ok = rank_hash(qr, uint32_t(m), sigma, hp, qend);
                     if (ranks_ok) {
+                        // prefix levels (KmxElemDev::n_levels): level L lists every (k - L)-mer's occurrences; the query is
+                        // answered at kk = k - L as if that were the element's k — its sigma^(kk - m) lists, its last-kmer letters
+                        const uint32_t L = min(uint32_t(k - m), el->n_levels);
+                        const uint32_t kk = k - L;
+                        const uint64_t R = ix->pw[kk - m];
                         hp *= R;                          // prefix_hash, :124-129
                         uint64_t klo, khi;                // key-index range of the prefix
-                        if (el->table_kind == KMX_TABLE_DENSE) {
+                        const KMX_GLOBAL uint32_t* run_offs = as_global(el->offs);
+                        uint64_t run_base = el->arena_base;
+                        if (L) {
+                            klo = hp; khi = hp + R;
+                            run_offs = as_global(ix->arena) + el->lvl_offs_at[L - 1];
+                            run_base = el->lvl_base[L - 1];
+                        } else if (el->table_kind == KMX_TABLE_DENSE) {
                             klo = hp; khi = hp + R;
                         } else {
                             const KMX_GLOBAL uint64_t* uk = as_global(el->ukeys);
@@ -317,21 +333,21 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
                             klo = first_key_at_least(hp);
                             khi = first_key_at_least(hp + R);
                         }
-                        const uint32_t lo = as_global(el->offs)[klo], hi = as_global(el->offs)[khi];
+                        const uint32_t lo = run_offs[klo], hi = run_offs[khi];
                         // check_last_kmer, :90-112: offsets n-k+i, i in [1, k-m], where no k-mer
                         // starts but the query still fits.  Bit j of aux <-> position n - j.
-                        const KMX_GLOBAL uint8_t* tail = as_global(ix->tail) + (ix->kmax - k);   // last k letters
+                        const KMX_GLOBAL uint8_t* tail = as_global(ix->tail) + (ix->kmax - kk);   // last kk letters
                         uint64_t tmask = 0;
-                        for (uint32_t i = 1; i + m <= k; ++i) {
+                        for (uint32_t i = 1; i + m <= kk; ++i) {
                             bool eq = true;
                             for (uint32_t t = 0; t < m; ++t) eq &= tail[i + t] == qr[t];
-                            if (eq) tmask |= uint64_t(1) << (k - i);
+                            if (eq) tmask |= uint64_t(1) << (kk - i);
                         }
                         const uint32_t len = hi - lo;
                         cnt = len + uint32_t(__popcll(tmask));
                         if (cnt) {
                             kind = KMX_KIND_PREFIX;
-                            src = el->arena_base + lo;
+                            src = run_base + lo;
                             aux = tmask;
                             key = klo;
                             c0 = uint32_t(khi - klo);     // number of runs
@@ -459,7 +475,7 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_stitch_tiny, n_resolved, n_prefix, n_prefix_big, n_prefix_merge, n_error, n_none, n_more;
+    unsigned int n_stitch, n_stitch_tiny, n_resolved, n_prefix, n_prefix_big, n_prefix_merge, n_prefix_mid, n_prefix_plain, n_error, n_none, n_more;
     unsigned long long words, pelems, hits;
     unsigned int max_runs;
     unsigned int base_stitch, base_stitch_tiny, base_prefix, base_prefix_big;
@@ -477,7 +493,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_stitch_tiny = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_prefix_merge = bc.n_error = bc.n_none = bc.n_more = 0;
+        bc.n_stitch = bc.n_stitch_tiny = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_prefix_merge = bc.n_prefix_mid = bc.n_prefix_plain = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = bc.hits = 0;
         bc.max_runs = 0;
     }
@@ -654,11 +670,15 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     }
     if (my_prefix) {
         const uint32_t plen = cnt - uint32_t(__popcll(aux));
-        if (KMX_PSORT_IS_SMALL(c0, plen)) {
+        if (c0 < 2 || plen < 2) {
+            loc = 0xFFFFFFFFu;                                   // one list (a prefix level's, or the only key): in order as it lies, not listed
+            atomicAdd(&bc.n_prefix_plain, 1u);
+        } else if (KMX_PSORT_IS_SMALL(c0, plen)) {
             loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
             if (KMX_PSORT_IS_MERGE(c0, plen)) atomicAdd(&bc.n_prefix_merge, 1u);
         } else {
             loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
+            if (plen <= KMX_PSORT_MID_CAP) atomicAdd(&bc.n_prefix_mid, 1u);
             if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: chunks sorted in LDS, then merged in global memory
                 atomicAdd(&bc.pelems, (unsigned long long)plen);
                 atomicMax(&bc.max_runs, (plen + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP);
@@ -702,6 +722,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         }
         if (bc.n_prefix) bc.base_prefix = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX], (unsigned long long)bc.n_prefix);
         if (bc.n_prefix_merge) atomicAdd(&ctr[KMX_CTR_PREFIX_MERGE], (unsigned long long)bc.n_prefix_merge);
+        if (bc.n_prefix_mid) atomicAdd(&ctr[KMX_CTR_PREFIX_MID], (unsigned long long)bc.n_prefix_mid);
+        if (bc.n_prefix_plain) atomicAdd(&ctr[KMX_CTR_PREFIX_PLAIN], (unsigned long long)bc.n_prefix_plain);
         if (bc.n_prefix_big) {
             bc.base_prefix_big = (unsigned int)atomicAdd(&ctr[KMX_CTR_PREFIX_BIG], (unsigned long long)bc.n_prefix_big);
             if (bc.pelems) atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
@@ -719,7 +741,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
             if (locs[it] & 0x80000000u) d.stitch_list[nq - 1 - (bc.base_stitch_tiny + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
             else d.stitch_list[bc.base_stitch + locs[it]] = uint32_t(q);
-        } else if (kinds[it] == KMX_KIND_PREFIX) {
+        } else if (kinds[it] == KMX_KIND_PREFIX && locs[it] != 0xFFFFFFFFu) {
             if (locs[it] & 0x80000000u) d.prefix_list[nq - 1 - (bc.base_prefix_big + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
             else d.prefix_list[bc.base_prefix + locs[it]] = uint32_t(q);
         }
@@ -2117,6 +2139,7 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
     typedef rec_t recv_t __attribute__((ext_vector_type(VW)));
     __shared__ __attribute__((aligned(16))) rec_t word[TILE];
     __shared__ rec_t wave_tot[KMX_BLOCK / KMX_WAVE];
+    __shared__ uint32_t tile_has_work;           // some slot of the tile is this kernel's to write
 
     const uint32_t tid = threadIdx.x;
     const uint64_t base = uint64_t(blockIdx.x) * TILE;
@@ -2128,8 +2151,10 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
         recv_t* w4 = reinterpret_cast<recv_t*>(word) + tid * (E / VW);
 #pragma unroll
         for (int j = 0; j < E / VW; ++j) w4[j] = recv_t(0);
+        if (tid == 0) tile_has_work = 0;
     }
     __syncthreads();
+    bool mine = false;
     for (uint64_t q = uint64_t(qa) + tid; q <= qb; q += KMX_BLOCK) {
         // three independent loads, issued together
         const uint64_t s = hit_off[q], e = hit_off[q + 1];
@@ -2139,6 +2164,7 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
             if (!(sv & SRC_SLOW)) {
                 const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
                 word[slot] = rec_t(sv + (base + slot - s) + (TILE - slot));
+                mine = true;
             } else if (sv & SRC_PREFIX) {
                 // [s, s + len): the contiguous slice of every k-mer with this prefix -> plain copy;
                 // [s + len, e): last-kmer positions (kmer_index.hpp:90-112) -> per-slot path
@@ -2151,18 +2177,23 @@ __global__ __launch_bounds__(KMX_BLOCK, (E <= 12 ? 8 : 6)) void k_fill(const Kmx
                     const bool sorted_elsewhere = len >= 2 && d.c0[q] >= 2;
                     word[slot] = sorted_elsewhere ? rec_t(ix->arena_elems + (TILE - slot))
                                                   : rec_t((sv & ~SRC_FLAGS) + (base + slot - s) + (TILE - slot));
+                    mine |= !sorted_elsewhere;
                 }
                 if (e > mid && mid < tile_end) {
                     const uint32_t slot = mid > base ? uint32_t(mid - base) : 0u;
                     word[slot] = rec_t(SLOW | rec_t(q - qa));
+                    mine = true;
                 }
             } else {
                 const uint32_t slot = s > base ? uint32_t(s - base) : 0u;
                 word[slot] = rec_t(SLOW | rec_t(q - qa));              // STITCH: written by k_compact
+                mine = true;
             }
         }
     }
+    if (mine) tile_has_work = 1;
     __syncthreads();
+    if (!tile_has_work) return;                  // a tile of nothing but slices the prefix kernels write (block-uniform)
 
     // 2. "last non-zero word so far" scan in blocked arrangement
     {
@@ -2519,9 +2550,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
         if (!KMX_PSORT_IS_SMALL(R, len) || KMX_PSORT_IS_MERGE(R, len) || R < 2 || len < 2) continue;   // wave-uniform
         const uint32_t* __restrict__ srcp = arena + (d.src[q] & ~SRC_FLAGS);
-        const uint64_t m = qoff[q + 1] - qoff[q];
-        const KmxPlanEntry pe = load_plan(ix, m);
-        const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
+        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);
         if (lane <= min(R, uint32_t(KMX_PSORT_MAX_RUNS))) bnd[wv][lane] = offs[lane] - offs[0];
         uint32_t* __restrict__ seg = out + hit_off[q];
         auto wsync = [] {
@@ -2716,8 +2745,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_small(const KmxIndex
         const uint32_t len = __builtin_amdgcn_readfirstlane(d.cnt[q] - uint32_t(__popcll(d.aux[q])));
         if (!KMX_PSORT_IS_MERGE(R, len)) continue;
         const uint32_t* __restrict__ srcp = arena + (d.src[q] & ~SRC_FLAGS);
-        const KmxPlanEntry pe = load_plan(ix, qoff[q + 1] - qoff[q]);
-        const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];
+        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);
         if (lane <= R) bnd[wv][lane] = offs[lane] - offs[0];
         for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][1 + t] = srcp[t];
         const uint32_t E = max(2u, (len + (KMX_WAVE - (R + 1) / 2) - 1) / (KMX_WAVE - (R + 1) / 2));
@@ -2989,41 +3017,49 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 }
 
 
-// PREFIX slices beyond k_prefix_sort_small's capacity: one 1024-thread block per chunk of up to KMX_PSORT_BLOCK_CAP
-// positions (a slice up to that length is one chunk and done after this; longer ones: k_prefix_merge_pass).  The
-// chunk is a row of ascending runs — the runs of the slice, cut at the chunk's ends — whose boundaries the block takes
-// from the element's offset table: up to KMX_PM_BLOCK_RUNS of them are merged (merge_runs_lds), more are sorted by the
-// bitonic network as before.
-#define KMX_PSB_THREADS 1024
-__global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
-                                                                        const uint64_t* __restrict__ qoff, QueryDesc d,
-                                                                        uint64_t n_prefix,
-                                                                        const uint64_t* __restrict__ hit_off,
-                                                                        const uint32_t* __restrict__ arena,
-                                                                        uint32_t* __restrict__ out,
-                                                                        const uint64_t* __restrict__ tile_off,
-                                                                        uint32_t* __restrict__ tmp)
+// PREFIX slices beyond k_prefix_sort_small's capacity: one block per chunk of up to KMX_PSORT_BLOCK_CAP positions (a slice
+// up to that length is one chunk and done after this; longer ones: k_prefix_merge_pass).  The chunk is a row of
+// ascending runs — the runs of the slice, cut at the chunk's ends — whose boundaries the block takes from the offset
+// table the slice came from: up to RUNS of them are merged (merge_runs_lds), more are sorted by the bitonic network.
+// Two shapes: 1024 threads around 128 KB of LDS (one block per CU), and, for slices up to KMX_PSORT_MID_CAP positions,
+// 256 threads around 33 KB (four per CU: one block's staging and copy-out overlap the others' rounds).
+template <int THREADS, int CAP, int RUNS>
+struct PsbShape {
+    static constexpr int EMAX = (CAP + (THREADS - RUNS / 2) - 1) / (THREADS - RUNS / 2);
+    static constexpr int WORDS = CAP + RUNS + EMAX + 5;      // staged chunk + sentinel cells + the reads of a chunk past its end
+};
+typedef PsbShape<1024, KMX_PSORT_BLOCK_CAP, 128> PsbBig;
+typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
+
+template <int THREADS, int CAP, int RUNS, bool MID>
+__global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
+                                                                const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                                uint64_t n_prefix,
+                                                                const uint64_t* __restrict__ hit_off,
+                                                                const uint32_t* __restrict__ arena,
+                                                                uint32_t* __restrict__ out,
+                                                                const uint64_t* __restrict__ tile_off,
+                                                                uint32_t* __restrict__ tmp)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // KMX_PSORT_BLOCK_CAP + KMX_PM_BLOCK_PAD words
-    __shared__ uint32_t bnd[KMX_PM_BLOCK_RUNS + 1];
-    __shared__ uint32_t ptab[4 * (KMX_PM_BLOCK_RUNS / 2 + 1)];
+    typedef PsbShape<THREADS, CAP, RUNS> Shape;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
+    __shared__ uint32_t bnd[RUNS + 1];
+    __shared__ uint32_t ptab[4 * (RUNS / 2 + 1)];
     __shared__ uint32_t runs[2];
     const uint32_t tid = threadIdx.x;
     for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
         const uint32_t q = d.prefix_list[i];
         const uint32_t R = d.c0[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-        const bool small = KMX_PSORT_IS_SMALL(R, len);
-        if (small || R < 2 || len < 2) continue;                                          // block-uniform
-        const uint32_t n_chunks = (len + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP;
+        if ((len <= KMX_PSORT_MID_CAP) != MID) continue;                                  // the other shape's (block-uniform)
+        const uint32_t n_chunks = (len + CAP - 1) / CAP;
         // where the chunks go: `out`, or the scratch buffer when the slice needs an odd number of merge passes
-        uint32_t* __restrict__ sorted = (prefix_merge_passes(len) & 1u) ? tmp + tile_off[i] * KMX_PM_TILE : out + hit_off[q];
-        const KmxPlanEntry pe = load_plan(ix, qoff[q + 1] - qoff[q]);
-        const KMX_GLOBAL uint32_t* offs = as_global(ix->elems[pe.elem].offs) + d.key[q];   // R + 1 run boundaries
+        uint32_t* __restrict__ sorted = (!MID && (prefix_merge_passes(len) & 1u)) ? tmp + tile_off[i] * KMX_PM_TILE : out + hit_off[q];
+        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);   // R + 1 run boundaries
         const uint32_t offs0 = offs[0];
         for (uint32_t c = blockIdx.y; c < n_chunks; c += gridDim.y) {
-            const uint32_t c_lo = c * KMX_PSORT_BLOCK_CAP;
-            const uint32_t c_len = min(uint32_t(KMX_PSORT_BLOCK_CAP), len - c_lo);
+            const uint32_t c_lo = c * CAP;
+            const uint32_t c_len = min(uint32_t(CAP), len - c_lo);
             const uint32_t* __restrict__ seg = arena + (d.src[q] & ~SRC_FLAGS) + c_lo;    // where the slice lies
             if (tid == 0) {
                 // the run that holds the chunk's first position, the first boundary at or behind its end
@@ -3034,7 +3070,7 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(const Kmx
             }
             __syncthreads();
             const uint32_t r0 = __builtin_amdgcn_readfirstlane(runs[0]), Rc = __builtin_amdgcn_readfirstlane(runs[1]);
-            const bool merge = Rc <= KMX_PM_BLOCK_RUNS;
+            const bool merge = Rc <= RUNS;
             if (merge && tid <= Rc) {
                 const uint32_t o = offs[r0 + tid] - offs0;
                 bnd[tid] = o <= c_lo ? 0u : min(o - c_lo, c_len);
@@ -3042,29 +3078,40 @@ __global__ __launch_bounds__(KMX_PSB_THREADS) void k_prefix_sort_block(const Kmx
             uint32_t n2 = 2;
             while (n2 < c_len) n2 <<= 1;
             const uint32_t n_stage = merge ? c_len : n2;
-            for (uint32_t t = tid; t < n_stage; t += KMX_PSB_THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
+            for (uint32_t t = tid; t < n_stage; t += THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
             __syncthreads();
             if (merge) {
-                const uint32_t E = max(2u, (c_len + (KMX_PSB_THREADS - (Rc + 1) / 2) - 1) / (KMX_PSB_THREADS - (Rc + 1) / 2));
-                merge_runs_lds<KMX_PM_BLOCK_EMAX, KMX_PSB_THREADS>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+                const uint32_t E = max(2u, (c_len + (THREADS - (Rc + 1) / 2) - 1) / (THREADS - (Rc + 1) / 2));
+                merge_runs_lds<Shape::EMAX, THREADS>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+            } else {
+                bitonic_lds(sbuf, n2, tid, uint32_t(THREADS), [] { __syncthreads(); });
             }
-            else bitonic_lds(sbuf, n2, tid, uint32_t(KMX_PSB_THREADS), [] { __syncthreads(); });
             uint32_t* __restrict__ dst = sorted + c_lo;
-            for (uint32_t t = tid; t < c_len; t += KMX_PSB_THREADS) dst[t] = sbuf[t];
+            for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
             __syncthreads();
         }
     }
 }
 
-void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix,
+// n_mid of the n_prefix listed queries have slices of at most KMX_PSORT_MID_CAP positions
+void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp)
 {
-    const size_t lds = size_t(KMX_PSORT_BLOCK_CAP + KMX_PM_BLOCK_PAD) * 4;
-    allow_big_lds(reinterpret_cast<const void*>(k_prefix_sort_block), lds, 0);
-    unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
-    const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks
-    hipLaunchKernelGGL(k_prefix_sort_block, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(KMX_PSB_THREADS), lds, s, ix, qoff, d,
-                       n_prefix, hit_off, arena, out, tile_off, tmp);
+    if (n_mid) {
+        auto fn = k_prefix_sort_block<256, KMX_PSORT_MID_CAP, 64, true>;
+        const size_t lds = size_t(PsbMid::WORDS) * 4;
+        const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 16);
+        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(256), lds, s, ix, qoff, d, n_prefix, hit_off, arena, out, tile_off, tmp);
+    }
+    if (n_prefix > n_mid) {
+        auto fn = k_prefix_sort_block<1024, KMX_PSORT_BLOCK_CAP, 128, false>;
+        const size_t lds = size_t(PsbBig::WORDS) * 4;
+        allow_big_lds(reinterpret_cast<const void*>(fn), lds, 0);
+        const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
+        const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks
+        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(1024), lds, s, ix, qoff, d, n_prefix, hit_off, arena, out,
+                           tile_off, tmp);
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -3324,5 +3371,36 @@ void launch_prefix_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_pref
 }
 
 uint64_t prefix_merge_tile() { return KMX_PM_TILE; }
+
+// ---------------------------------------------------------------------------
+// Prefix levels (KmxElemDev::n_levels) are built by the engine itself: the batch of ALL m-mers, in rank-hash order, is
+// searched like any other batch; its hit_off / positions are the level.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_all_kmers(uint32_t m, uint32_t sigma, uint64_t nq, uint8_t* __restrict__ qranks,
+                                                         uint64_t* __restrict__ qoff)
+{
+    const uint64_t h = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (h > nq) return;
+    qoff[h] = h * m;
+    if (h == nq) return;
+    uint64_t v = h;
+    for (uint32_t t = m; t-- > 0;) { qranks[h * m + t] = uint8_t(v % sigma); v /= sigma; }     // Horner's digits, last letter first
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_narrow_offsets(const uint64_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ out)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (i < n) out[i] = uint32_t(in[i]);
+}
+
+void launch_all_kmers(hipStream_t s, uint32_t m, uint32_t sigma, uint64_t nq, uint8_t* d_qranks, uint64_t* d_qoff)
+{
+    hipLaunchKernelGGL(k_all_kmers, dim3(blocks_for(nq + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, m, sigma, nq, d_qranks, d_qoff);
+}
+
+void launch_narrow_offsets(hipStream_t s, const uint64_t* d_in, uint64_t n, uint32_t* d_out)
+{
+    hipLaunchKernelGGL(k_narrow_offsets, dim3(blocks_for(n, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_in, n, d_out);
+}
 
 } // namespace kmx

@@ -5,6 +5,9 @@
 #include <stdint.h>
 #include "../../include/kmx.h"
 
+#define KMX_MAX_LEVELS 3            // prefix levels per element (KmxElemDev::n_levels)
+#define KMX_DEFAULT_PREFIX_LEVELS 2  // kmx_options::prefix_levels == 0 and no KMX_PREFIX_LEVELS in the environment
+
 // One slot of the open-addressing table that replaces
 // robin_hood::unordered_map<size_t, std::vector<position_t>> (kmer_index.hpp:52).
 // cnt == 0 marks an empty slot (every stored key owns >= 1 position).
@@ -57,7 +60,16 @@ struct KmxElemDev {
     const uint8_t* cnt8;
     uint64_t cell_base;    // arena index of cell 0 (a multiple of 32)
     uint32_t cell_shift;   // log2 of the cell size in positions: 3, 4 or 5 (32-, 64- or 128-byte cells)
-    uint32_t reserved0;
+    // PREFIX LEVELS (dense elements; derived when the index is installed, not part of the image): level L = 1 .. n_levels holds,
+    // for every (k - L)-mer in rank-hash order, the ascending list of ALL its occurrences — what get_position_for_all_kmer_with_prefix
+    // + check_last_kmer + to_vector() (kmer_index.hpp:90-148, kmer_index_result.hpp:244-260) return for it, i.e. the sigma^L
+    // buckets merged once, ahead of time, instead of per query.  A query of m < k letters is answered from level
+    // min(k - m, n_levels): from ONE list when the level has its length, otherwise from sigma^(k - L - m) lists instead of
+    // sigma^(k - m) buckets.  lvl_offs_at[L - 1]: arena index of the level's sigma^(k-L) + 1 list boundaries (relative to
+    // lvl_base[L - 1], the arena index of its n - (k - L) + 1 positions).
+    uint32_t n_levels;
+    uint64_t lvl_offs_at[KMX_MAX_LEVELS];
+    uint64_t lvl_base[KMX_MAX_LEVELS];
 };
 
 // Planner entry for one query length m — what kmer_index::search consults at
@@ -119,6 +131,8 @@ struct KmxIndexDev {
 // ... up to KMX_PSORT_BLOCK_CAP positions (any number of runs) by one 1024-thread block (bitonic sort in
 // 128 KB of LDS, k_prefix_sort_block); beyond that the global merge passes.
 #define KMX_PSORT_BLOCK_CAP 32768
+// of those, slices up to KMX_PSORT_MID_CAP positions take a 256-thread block with a quarter of the LDS (four per CU)
+#define KMX_PSORT_MID_CAP 8192
 
 // k_small — the latency path of small batches (kmer_index::search(query) is a batch of one): ONE launch of up to
 // KMX_SMALL_BLOCKS workgroups, 256 queries each, that read the queries from and write the complete result to ONE page-locked
@@ -174,7 +188,6 @@ static inline KmxSmallLayout kmx_small_layout(uint32_t blocks)
 
 // Counter block written by the lookup kernel and read back once per batch.
 enum {
-    KMX_CTR_EXACT = 0,
     KMX_CTR_STITCH = 1,
     KMX_CTR_PREFIX = 2,
     KMX_CTR_ERROR = 3,
@@ -189,5 +202,7 @@ enum {
     KMX_CTR_STITCH_TINY = 12, // STITCH queries with at most KMX_VTINY candidates and filter-bucket entries (listed from the BACK of stitch_list)
     KMX_CTR_STITCH_RESOLVED = 13, // STITCH queries k_lookup resolved by itself (tiny first bucket, survivors one run of it)
     KMX_CTR_PREFIX_MERGE = 14, // small PREFIX queries of the merge class (KMX_PSORT_IS_MERGE): k_prefix_merge_small has work
+    KMX_CTR_PREFIX_MID = 15,   // of KMX_CTR_PREFIX_BIG: slices of at most KMX_PSORT_MID_CAP positions (k_prefix_sort_block's 256-thread variant)
+    KMX_CTR_PREFIX_PLAIN = 0,  // PREFIX queries answered by ONE list (nothing to sort: on no work list)
     KMX_CTR_COUNT = 16
 };

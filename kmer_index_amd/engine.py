@@ -38,7 +38,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("device", C.c_int32), ("table_kind", C.c_uint32),
                 ("n_threads", C.c_uint32), ("query_size_range", C.c_uint32), ("keep_host_arena", C.c_uint32),
                 ("host_flatten", C.c_uint32), ("no_aligned_copy", C.c_uint32),
-                ("n_devices", C.c_uint32), ("devices", C.c_int32 * KMX_MAX_DEVICES)]
+                ("n_devices", C.c_uint32), ("devices", C.c_int32 * KMX_MAX_DEVICES), ("prefix_levels", C.c_int32)]
 
 
 class KernelStat(C.Structure):
@@ -250,9 +250,10 @@ class Index:
     """kmx_index handle: the flattened kmer_index<alphabet_t, uint32_t, ks...> resident in HBM."""
 
     def __init__(self, ranks, sigma, ks, table=TABLE_AUTO, device=-1, n_threads=0, keep_host_arena=False,
-                 query_size_range=0, host_flatten=False, aligned_copy=True, devices=None):
+                 query_size_range=0, host_flatten=False, aligned_copy=True, devices=None, prefix_levels=0):
         """devices: None = one replica on `device` (KMX_DEVICES in the environment may widen it); a list of ordinals =
-        built on devices[0] and replicated onto the others (host-buffer searches then shard over the replicas)."""
+        built on devices[0] and replicated onto the others (host-buffer searches then shard over the replicas).
+        prefix_levels: kmx_options.prefix_levels (0 = default, -1 = none, N = at most N pre-merged levels per element)."""
         ranks = np.ascontiguousarray(ranks, np.uint8)
         ks = np.ascontiguousarray(ks, np.uint32)
         self.ks = ks.tolist()
@@ -267,19 +268,21 @@ class Index:
         o.keep_host_arena = int(keep_host_arena)
         o.host_flatten = int(host_flatten)
         o.no_aligned_copy = int(not aligned_copy)
+        o.prefix_levels = int(prefix_levels)
         _set_devices(o, devices)
         self._h = C.c_void_p()
         _check(lib().kmx_index_build(ranks.ctypes.data, ranks.size, self.sigma, ks.ctypes.data, ks.size,
                                      C.byref(o), C.byref(self._h)))
 
     @classmethod
-    def load(cls, path, device=-1, keep_host_arena=False, devices=None):
+    def load(cls, path, device=-1, keep_host_arena=False, devices=None, prefix_levels=0):
         """kmx_index_load: an index from an image written by save()."""
         self = cls.__new__(cls)
         o = Options()
         o.struct_size = C.sizeof(Options)
         o.device = device
         o.keep_host_arena = int(keep_host_arena)
+        o.prefix_levels = int(prefix_levels)
         _set_devices(o, devices)
         self._h = C.c_void_p()
         _check(lib().kmx_index_load(os.fsencode(path), C.byref(o), C.byref(self._h)))

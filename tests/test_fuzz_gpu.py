@@ -91,7 +91,7 @@ def test_random_index_and_queries(engine, orc, seed):
     nkeys_max = max(sigma ** k for k in ks)
     tables = [engine.TABLE_AUTO, engine.TABLE_OPEN] + ([engine.TABLE_DENSE] if nkeys_max <= (1 << 24) else [])
     table = tables[int(rng.integers(0, len(tables)))]
-    kw = dict(table=table, aligned_copy=bool(rng.integers(0, 2)), host_flatten=bool(rng.integers(0, 2)))
+    kw = dict(table=table, aligned_copy=bool(rng.integers(0, 2)), host_flatten=bool(rng.integers(0, 2)), prefix_levels=[-1, 0, 1, 3][seed % 4])
     case = f"seed={seed} sigma={sigma} ks={ks} n={text.size} text={style} {kw} queries={len(qs)}"
     idx = engine.Index(text, sigma, ks, **kw)
     flags = engine.SEARCH_KEEP_MASKS if seed % 3 == 0 else engine.SEARCH_DEFAULT

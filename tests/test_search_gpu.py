@@ -568,7 +568,7 @@ def test_prefix_sort_all_size_classes(engine, orc):
     """m < k slices of every class: few runs / short (wave-level LDS rank pass), mid-size or many runs (block-level
     bitonic sort in LDS), and beyond 32 K positions (global merge passes) — all equal the oracle."""
     text = synth.ranks(606, 600_000, 4)
-    idx = engine.Index(text, 4, [10])
+    idx = engine.Index(text, 4, [10], prefix_levels=-1)           # no pre-merged levels: every slice is merged per query
     oidx = orc.Index(text, 4, [10])
     qs = []
     for m, cnt in ((9, 40), (8, 40), (7, 30), (6, 20), (5, 10), (4, 6), (3, 4), (2, 2)):     # 4 .. 65536 runs; 2 .. 37 K hits
@@ -584,8 +584,69 @@ def test_prefix_sort_all_size_classes(engine, orc):
     assert (kd == engine.KIND_PREFIX).all()
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
     k = idx.stats()
-    assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_merge_small"]["launches"]
-    assert k["k_prefix_sort_block"]["launches"] and k["k_prefix_merge_pass"]["launches"]
+    assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_prefix_merge_pass"]["launches"]
+    # the same classes with LONG runs (146 positions per 6-mer): 4 runs / 586 positions (wave-level merge), 16 runs / 2.3 K and
+    # 64 runs / 9.4 K (the two shapes of the block-level merge), 256 and 1024 runs (chunks + merge passes)
+    idx6 = engine.Index(text, 4, [6], prefix_levels=-1)
+    oidx6 = orc.Index(text, 4, [6])
+    qs = [text[s0:s0 + m].copy() for m, cnt in ((5, 60), (4, 40), (3, 20), (2, 6), (1, 2)) for s0 in range(1000, 1000 + 37 * cnt, 37)]
+    qs += [text[text.size - m:].copy() for m in (5, 3)]
+    qranks, qoff = pack(qs)
+    idx6.stats_enable(True)
+    ho, pos, st, kd = idx6.search(qranks, qoff).host()
+    o_off, o_pos, o_st, _ = oidx6.search_batch(qranks, qoff, n_threads=4)
+    assert (kd == engine.KIND_PREFIX).all()
+    assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    k = idx6.stats()
+    assert k["k_prefix_merge_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_prefix_merge_pass"]["launches"]
+
+
+@pytest.mark.parametrize("sigma,ks,levels", [(4, [10], 0), (4, [10], 1), (4, [10], 3), (4, [6, 9, 12], 0), (5, [8], 0), (20, [4], 0),
+                                             (4, [9, 10], 3)])
+def test_prefix_levels_answer_like_the_merge(engine, orc, sigma, ks, levels):
+    """Prefix levels (kmx_options.prefix_levels): the lists of every (k - L)-mer, merged once when the index is installed.
+    A sub-k query then copies one list (length k - L) or merges sigma^L times fewer of them (shorter ones) — same positions,
+    same order, same last-kmer positions as the oracle, for every sub-k length of every element, and the same as the index
+    without levels; the memory they cost shows in device_bytes; queries a level answers outright run no sort kernel."""
+    text = synth.ranks(4242 + sigma, 300_000, sigma)
+    with_lv = engine.Index(text, sigma, ks, prefix_levels=levels)
+    without = engine.Index(text, sigma, ks, prefix_levels=-1)
+    oidx = orc.Index(text, sigma, ks)
+    assert with_lv.info()["device_bytes"] >= without.info()["device_bytes"] + 4 * (text.size - max(ks))
+    qs = []
+    rng = np.random.default_rng(7)
+    for m in range(1, max(ks)):
+        if sigma ** (min(k for k in ks if k >= m) - m) > 10_000:       # keep the oracle's fan-out cheap
+            continue
+        for t in range(6):
+            s0 = int(rng.integers(0, text.size - m))
+            qs.append(text[s0:s0 + m].copy())
+        qs.append(text[text.size - m:].copy())                         # ends the text: last-kmer positions
+        qs.append(text[text.size - m - 1:text.size - 1].copy())
+        qs.append(rng.integers(0, sigma, m).astype(np.uint8))
+    qranks, qoff = pack(qs)
+    o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+    for idx in (with_lv, without):
+        ho, pos, st, kd = idx.search(qranks, qoff).host()
+        assert np.array_equal(st, o_st.astype(np.uint8))
+        assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+    # a batch of nothing but (k - 1)-letter queries on the smallest k: answered from level 1, nothing to sort
+    k0 = min(ks)
+    if k0 > 1:
+        sub = [q for q in qs if len(q) == k0 - 1] * 1000           # (more than the one-launch latency path takes)
+        sq, so = pack(sub)
+        with_lv.stats_enable(True)
+        with_lv.stats_reset()
+        r = with_lv.search(sq, so)
+        kst = with_lv.stats()
+        assert kst["k_fill"]["launches"] and not kst["k_small"]["launches"]
+        assert not any(kst[name]["launches"] for name in ("k_prefix_sort_small", "k_prefix_merge_small", "k_prefix_sort_block", "k_prefix_merge_pass"))
+        a = r.host()
+        b = without.search(sq, so).host()
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y)
+    with_lv.close()
+    without.close()
 
 
 def test_prefix_slices_of_one_long_run_and_of_lopsided_runs(engine, orc):
@@ -596,8 +657,8 @@ def test_prefix_slices_of_one_long_run_and_of_lopsided_runs(engine, orc):
     text = np.tile(unit, 40_000)
     text[77_001] = 3                                   # a broken period: one-position runs next to the long ones
     text[5] = 3
-    for ks in ([12], [9]):
-        idx = engine.Index(text, 4, ks, table=engine.TABLE_OPEN)
+    for ks, levels in (([12], -1), ([9], -1), ([9], 0)):
+        idx = engine.Index(text, 4, ks, table=engine.TABLE_OPEN if levels else engine.TABLE_DENSE, prefix_levels=levels)
         oidx = orc.Index(text, 4, ks)
         qs = [text[s0:s0 + m].copy() for m in (1, 2, 3, 5, 8) for s0 in (0, 1, 2, 30, 76_995, 77_000, text.size - 8)]
         qranks, qoff = pack(qs)
