@@ -66,6 +66,9 @@ def parse_args(argv=None):
                          "lookup / scan of step i+1 may run under the tail of step i's fill")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the extra leg that times the same steps with the handles on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="N=1, config 2 only: skip the legs that run BASELINE configs[2..4] (--config 3/4/5) for the same K steps and "
+                         "report them as other_configs in the same JSON line")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
     ap.add_argument("--verify", type=int, default=20000, help="queries checked against the oracle after timing")
@@ -190,28 +193,32 @@ def worker(args):
     log(f"index built+uploaded in {time.time() - t0:.1f}s: {info}")
 
     # this rank's query shard: letters [rank*nq*m, (rank+1)*nq*m) of the config's query stream
+    def make_queries(text_, sigma_, nq_, qlens_, planted_, qseed_):
+        if planted_ == 0.0:
+            m_ = qlens_[0]
+            qr = np.empty(nq_ * m_, np.uint8)
+            chunk = 1 << 24
+            for s in range(0, nq_ * m_, chunk):
+                e = min(nq_ * m_, s + chunk)
+                z = synth.u64_stream(qseed_, e - s, rank * nq_ * m_ + s)
+                qr[s:e] = (((z >> np.uint64(32)) * np.uint64(sigma_)) >> np.uint64(32)).astype(np.uint8)
+            qo = np.arange(nq_ + 1, dtype=np.uint64) * np.uint64(m_)
+            if args.sort_queries:
+                h = np.zeros(nq_, np.uint64)
+                q2 = qr.reshape(nq_, m_)
+                for j in range(m_):
+                    h = h * np.uint64(sigma_) + q2[:, j]
+                qr = np.ascontiguousarray(q2[np.argsort(h, kind="stable")]).reshape(-1)
+            return m_, qr, qo
+        qr, qo = synth.mixed_queries(qseed_ + 7919 * rank, text_, nq_, qlens_, sigma_, planted_frac=planted_)
+        return 0, qr, qo
+
     nq = args.nq
-    if planted == 0.0:
-        m = qlens[0]
-        qr_host = np.empty(nq * m, np.uint8)
-        chunk = 1 << 24
-        for s in range(0, nq * m, chunk):
-            e = min(nq * m, s + chunk)
-            z = synth.u64_stream(qseed, e - s, rank * nq * m + s)
-            qr_host[s:e] = (((z >> np.uint64(32)) * np.uint64(args.sigma)) >> np.uint64(32)).astype(np.uint8)
-        qoff_host = np.arange(nq + 1, dtype=np.uint64) * np.uint64(m)
-        if args.sort_queries:
-            h = np.zeros(nq, np.uint64)
-            q2 = qr_host.reshape(nq, m)
-            for j in range(m):
-                h = h * np.uint64(args.sigma) + q2[:, j]
-            qr_host = np.ascontiguousarray(q2[np.argsort(h, kind="stable")]).reshape(-1)
-    else:
-        m = 0
-        qr_host, qoff_host = synth.mixed_queries(qseed + 7919 * rank, text, nq, qlens, args.sigma, planted_frac=planted)
+    m, qr_host, qoff_host = make_queries(text, args.sigma, nq, qlens, planted, qseed)
     n_letters = int(qoff_host[-1])
     d_qr = torch.from_numpy(qr_host).to(dev)
     d_qoff = torch.from_numpy(qoff_host.view(np.int64)).to(dev)
+    main_queries = (d_qr, d_qoff, nq)
     torch.cuda.synchronize()
 
     depth = max(1, args.pipeline)
@@ -227,7 +234,8 @@ def worker(args):
     # ------------------------------------------------------------------------------------------------------------
     sh_streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(max(depth, 2) - 1)]
 
-    def run_sharded(index, steps, warmup, collect_stats, n_streams=1):
+    def run_sharded(index, steps, warmup, collect_stats, n_streams=1, queries=None):
+        d_qr, d_qoff, nq = queries or main_queries
         n_streams = max(1, min(n_streams, depth))
         results = [engine.Result() for _ in range(depth)]
         flags = engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT
@@ -345,6 +353,52 @@ def worker(args):
             r_.close()
         return out
 
+    def reread_ok(text_, qr_, qo_, hit_off_, positions_, nv_):
+        # every reported position of the first nv_ queries re-reads to its query; lists ascending without repeats
+        cntv = np.diff(hit_off_[:nv_ + 1]).astype(np.int64)
+        qi = np.repeat(np.arange(nv_), cntv)
+        pos = positions_[:int(hit_off_[nv_])].astype(np.int64)
+        lens = np.diff(qo_[:nv_ + 1]).astype(np.int64)
+        ok = True
+        for j in range(int(lens.max()) if nv_ else 0):
+            sel = lens[qi] > j
+            ok &= bool(np.array_equal(text_[pos[sel] + j], qr_[qo_[qi[sel]].astype(np.int64) + j]))
+        if pos.size > 1:
+            same_q = qi[1:] == qi[:-1]
+            ok &= bool((pos[1:][same_q] > pos[:-1][same_q]).all())
+        return bool(ok)
+
+    # BASELINE configs[2..4] for the same K steps each, reported beside the headline (N = 1 only): own text, own index, the
+    # same pipeline as `value`, checked by re-reading the first 2000 queries' positions and by the hit total of a second pass
+    def other_config(cfg):
+        sg, n_c, ks_c, nq_c, ql_c, pl_c, ts_c, qs_c = CFG[cfg]
+        t_c = time.time()
+        text_c = synth.ranks(ts_c, n_c, sg)
+        idx_c = engine.Index(text_c, sg, ks_c, device=dev_index)
+        info_c = idx_c.info()
+        _, qr_c, qo_c = make_queries(text_c, sg, nq_c, ql_c, pl_c, qs_c)
+        q_c = (torch.from_numpy(qr_c).to(dev), torch.from_numpy(qo_c.view(np.int64)).to(dev), nq_c)
+        el_c, res_c, st_c = run_sharded(idx_c, args.steps, args.warmup, True, 1, q_c)
+        cn = res_c[0].counts()
+        ho, po, _, _ = res_c[0].host(copy=False)
+        ok = reread_ok(text_c, qr_c, qo_c, ho, po, min(2000, nq_c)) and all(r_.counts()["n_hits"] == cn["n_hits"] for r_ in res_c)
+        ms = el_c / args.steps * 1e3
+        fill_c = st_c.get("k_fill", {"launches": 0, "total_ms": 0.0})
+        f_ms = fill_c["total_ms"] / max(fill_c["launches"], 1)
+        job_b = float(int(qo_c[-1])) + 24.0 * nq_c + 8.0 * cn["n_hits"]                     # the same R + W definition as the headline's
+        o = {"value": round(nq_c * args.steps / el_c / 1e6, 3), "unit": "M queries/s", "ms_per_step": round(ms, 4),
+             "job_frac": round(job_b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+             "k_fill_frac": round(8.0 * cn["n_hits"] / (f_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4) if f_ms > 0 else None,
+             "verified": bool(ok), "queries": nq_c, "hits_per_step": cn["n_hits"], "index_device_bytes": info_c["device_bytes"],
+             "kernels_avg_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st_c.items() if v["launches"]},
+             "workload": f"BASELINE configs[{cfg - 1}]: sigma={sg} text {n_c}, ks={ks_c}, lengths {ql_c}, planted {pl_c}", "wall_s": None}
+        for r_ in res_c:
+            r_.close()
+        idx_c.close()
+        del q_c
+        o["wall_s"] = round(time.time() - t_c, 1)
+        return o
+
     # (KMX_BENCH_INIT_PG: a 1-rank process group, so that a 1-GPU box still drives the RCCL code path end to end)
     want_gather = backend is not None and args.gather in ("both", "hits")
     elapsed, results, stats = run_sharded(idx, args.steps, args.warmup, True, args.streams)
@@ -416,6 +470,12 @@ def worker(args):
             t1 = time.perf_counter()
             oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=T, keep_hits=False, reference_pool=ref_pool)
             dt = time.perf_counter() - t1
+            # "T = hardware_concurrency, also T = 1" — the same sample on every usable core (chunked >= 4 T by the batch)
+            dt_all = None
+            if usable > T:
+                t1 = time.perf_counter()
+                oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=usable, keep_hits=False, reference_pool=ref_pool)
+                dt_all = time.perf_counter() - t1
             n1 = min(ns, 1_000_000)                               # the same restatement on one thread ("also T=1")
             t1 = time.perf_counter()
             oidx.search_batch(qr_host[:n1 * m], qoff_host[:n1 + 1], n_threads=1, keep_hits=False)
@@ -431,24 +491,30 @@ def worker(args):
                                       + ("the reference's own thread_pool (thread_pool.{hpp,cpp} compiled from its sources into oracle/_ref)" if ref_pool
                                          else "the restated thread pool (oracle/_ref not built)")
                                       + f" ({T} threads of {usable} usable, {cpu_model}; std::unordered_map buckets in place of robin_hood), {dt:.1f}s wall",
-                            "single_thread_value": round(n1 / dt1 / 1e6, 4), "single_thread_sample": f"first {n1} queries, {dt1:.1f}s"}
+                            "single_thread_value": round(n1 / dt1 / 1e6, 4), "single_thread_sample": f"first {n1} queries, {dt1:.1f}s",
+                            "all_cores_value": round(ns / dt_all / 1e6, 4) if dt_all else None, "all_cores": usable if dt_all else None,
+                            "all_cores_sample": f"the same {ns} queries on all {usable} usable hardware threads, {dt_all:.1f}s wall" if dt_all else None}
             o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
             oidx.close()
         else:
             # no oracle index in this leg: every reported position of the first queries must re-read to its query
-            nv = min(nv, 2000)
-            cntv = np.diff(hit_off[:nv + 1]).astype(np.int64)
-            qi = np.repeat(np.arange(nv), cntv)
-            pos = positions[:int(hit_off[nv])].astype(np.int64)
-            lens = np.diff(qoff_host[:nv + 1]).astype(np.int64)
-            ok = True
-            for j in range(int(lens.max()) if nv else 0):
-                sel = lens[qi] > j
-                ok &= bool(np.array_equal(text[pos[sel] + j], qr_host[qoff_host[qi[sel]].astype(np.int64) + j]))
-            verified = bool(ok)
+            verified = reread_ok(text, qr_host, qoff_host, hit_off, positions, min(nv, 2000))
         if not verified:
             log("VERIFICATION FAILED")
+
+    other = None
+    if world == 1 and args.config == 2 and not args.no_other_configs and not args.sort_queries and args.nq == nq_cfg and args.n == n_cfg:
+        other = {}
+        for cfg in (3, 4, 5):
+            try:
+                other[str(cfg)] = other_config(cfg)
+                log(f"config {cfg}: {other[str(cfg)]['value']} M queries/s, verified={other[str(cfg)]['verified']}, {other[str(cfg)]['wall_s']} s")
+            except Exception as e:                                    # reported, not fatal: the headline stands on its own
+                other[str(cfg)] = {"error": f"{type(e).__name__}: {e}"}
+        if any(isinstance(v, dict) and v.get("verified") is False for v in other.values()):
+            verified = False
+            log("VERIFICATION FAILED in other_configs")
 
     out = None
     if rank == 0:
@@ -509,6 +575,7 @@ def worker(args):
             "two_streams": two_streams,
             "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
+            "other_configs": other,
             "kernels_avg_ms": kernels_ms,
             "verified_vs_oracle": verified,
         }
@@ -524,9 +591,19 @@ def worker(args):
                 return
             if rank == 0:
                 out["gather_hits"] = {"error": f"the gather leg did not finish within {deadline:.0f} s; abandoned"}
+                if args.gather == "hits":                             # the gather leg WAS the metric asked for: no number, not the other leg's
+                    out["value"], out["gather_failed"] = None, True
                 print(json.dumps(out), flush=True)
             log(f"gather leg abandoned after {deadline:.0f} s")
-            os._exit(0 if (verified is None or verified) else 4)
+            os._exit(gather_exit_code())
+
+        def gather_exit_code():
+            # --gather hits asked for the gather metric: a leg that failed or was abandoned is a failed run (5), not rc 0 with
+            # the sharded leg's numbers; with --gather both the sharded leg is the metric and the line stands
+            if not (verified is None or verified):
+                return 4
+            return 5 if (args.gather == "hits" and rank == 0) else 0      # (rank 0 only, after it has printed: a launcher ends the
+                                                                             # other ranks when one fails)
 
         guard = threading.Timer(deadline, give_up)
         guard.daemon = True
@@ -567,11 +644,13 @@ def worker(args):
                     out["config"]["gather"] = "hits"
             else:
                 out["gather_hits"] = {"error": gather_err}
+                if args.gather == "hits":
+                    out["value"], out["gather_failed"] = None, True
     if rank == 0:
         print(json.dumps(out), flush=True)
     if want_gather and gather_err is not None:                        # the process group may be unusable: no teardown through it
         sys.stderr.flush()
-        os._exit(0 if (verified is None or verified) else 4)
+        os._exit(gather_exit_code())
     for r_ in results:
         r_.close()
     idx.close()

@@ -91,6 +91,15 @@ def test_a_gather_leg_that_never_returns_costs_only_its_own_object():
 
 
 @pytest.mark.gpu
+def test_a_failed_gather_leg_is_a_failed_run_when_the_gather_was_the_metric():
+    """--gather hits asks for the gather leg's number as `value`: when that leg is abandoned the line says so (value null,
+    gather_failed) and the ranks exit 5 — never rc 0 with the sharded leg's numbers under the gather's name."""
+    rc, out, err = _run(["--gpus", "2", "--oversubscribe", "--gather", "hits"] + SMALL, env_extra={"KMX_BENCH_GATHER_DEADLINE": "0.001"})
+    assert rc == 5, err[-2000:]
+    assert out["value"] is None and out["gather_failed"] is True and "did not finish" in out["gather_hits"]["error"]
+
+
+@pytest.mark.gpu
 def test_n_ranks_over_rccl_when_the_box_has_the_devices():
     """The real thing: one rank per GPU over RCCL/xGMI.  Skipped (not faked with gloo) on a 1-GPU box."""
     n = _n_devices()
