@@ -66,6 +66,8 @@ def parse_args(argv=None):
                          "lookup / scan of step i+1 may run under the tail of step i's fill")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the extra leg that times the same steps with the handles on two streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-api", action="store_true",
+                    help="N=1, config 2 only: skip the PCIe-inclusive leg (kmx_search_batch + kmx_result_view from / to host memory)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="N=1, config 2 only: skip the legs that run BASELINE configs[2..4] (--config 3/4/5) for the same K steps and "
                          "report them as other_configs in the same JSON line")
@@ -503,6 +505,35 @@ def worker(args):
         if not verified:
             log("VERIFICATION FAILED")
 
+    # ---- the PCIe-inclusive rate of the host-buffer form (never `value`): queries in pageable host memory in, hit lists in
+    # the result's host memory out — one pass, and streamed in four chunks (chunk i's device-to-host copy under chunk i+1's search)
+    host_api = None
+    if world == 1 and args.config == 2 and not args.no_host_api and rank == 0:
+        def host_leg(chunk):
+            if chunk:
+                os.environ["KMX_HOST_CHUNK"] = str(chunk)
+            try:
+                r_h = engine.Result()
+                best = None
+                for _ in range(2):                                    # the first pass sizes (and page-locks) the host views
+                    t1 = time.perf_counter()
+                    idx.search(qr_host, qoff_host, result=r_h)
+                    ho_h, po_h, _, _ = r_h.host(copy=False)
+                    dt_h = time.perf_counter() - t1
+                    best = dt_h if best is None else min(best, dt_h)
+                same_h = int(ho_h[-1]) == counts["n_hits"] and po_h.size == counts["n_hits"]
+                r_h.close()
+                return best, same_h
+            finally:
+                os.environ.pop("KMX_HOST_CHUNK", None)
+        dt_one, ok_one = host_leg(0)
+        dt_ch, ok_ch = host_leg(max(nq // 4, 1))
+        host_api = {"value": round(nq / dt_one / 1e6, 3), "unit": "M queries/s", "ms": round(dt_one * 1e3, 2),
+                    "hits_GBps": round(4.0 * counts["n_hits"] / dt_one / 1e9, 1), "same_hit_total": bool(ok_one),
+                    "chunked_value": round(nq / dt_ch / 1e6, 3), "chunked_ms": round(dt_ch * 1e3, 2), "chunked_same_hit_total": bool(ok_ch),
+                    "what": "kmx_search_batch (queries from pageable host memory) + kmx_result_view (hit lists in host memory), end to end; "
+                            "chunked: the same batch streamed through the device in 4 chunks, chunk i's copies under chunk i+1's search"}
+
     other = None
     if world == 1 and args.config == 2 and not args.no_other_configs and not args.sort_queries and args.nq == nq_cfg and args.n == n_cfg:
         other = {}
@@ -575,6 +606,7 @@ def worker(args):
             "two_streams": two_streams,
             "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
+            "host_api": host_api,
             "other_configs": other,
             "kernels_avg_ms": kernels_ms,
             "verified_vs_oracle": verified,

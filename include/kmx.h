@@ -118,6 +118,14 @@ typedef struct kmx_options {
                                       new search into it, or kmx_index_free of its index, which completes every search
                                       still pending on the index before it releases anything).  d_qranks and d_qoff must
                                       stay alive until then.  Two results used in turn keep the GPU busy across batches. */
+#define KMX_SEARCH_REFERENCE_PLAN 8u /* answer every query from the element the REFERENCE's planner names (choose_search_scheme,
+                                      kmer_index.hpp:407-476).  By default a single-k query longer than its k is answered from
+                                      the largest k of the index that fits it instead of the k that wastes the fewest letters
+                                      (kmer_index.hpp:465-473): the buckets to intersect are shorter by sigma^(difference) and
+                                      the position lists are the same — but which of KMX_KIND_NONE / KMX_KIND_STITCH a query
+                                      WITHOUT hits reports may differ (an absent part of the larger k ends the lookup early).
+                                      KMX_SEARCH_KEEP_MASKS implies this flag: candidate runs and mask words are the
+                                      reference's result object.  kmx_plan always reports the reference's tables.           */
 
 typedef struct kmx_index kmx_index;
 typedef struct kmx_result kmx_result;

@@ -180,6 +180,8 @@ struct kmx_index {
     std::vector<void*> allocs;          // device allocations owned by the index
     uint64_t device_bytes = 0;
     KmxIndexDev* d_index = nullptr;     // device copy of the header
+    KmxIndexDev* d_index_fast = nullptr; // the same header around the engine's own planner table (kmx::make_fast_plan_entries): every search but KEEP_MASKS ones
+    const KmxPlanEntry* d_plan_fast = nullptr;
     const uint32_t* d_arena = nullptr;  // the position arena (also in the header; passed to kernels directly)
     unsigned long long* d_dbg = nullptr; // KMX_CHECKED violation records
     struct ElemSizes { size_t n_offs, n_slots, n_ukeys, n_aoffs; };
@@ -246,6 +248,7 @@ struct kmx_result {
     bool chunked = false;                  // (parent) its parts are chunks
     bool host_chunk = false;               // (part) lives in host memory only
     kmx_result* worker = nullptr;
+    kmx_result* worker2 = nullptr;         // ... and a second one: chunk i's results leave for the host while chunk i + 1 is searched
 
     size_t device_bytes() const
     {
@@ -352,6 +355,24 @@ static uint32_t cell_shift_for(uint32_t table_kind, uint64_t n_keys, uint64_t np
     return shift;
 }
 static inline uint64_t up32_elems(uint64_t v) { return (v + 31) & ~uint64_t(31); }
+
+// The two device copies of the header follow ix->h_header (d_index: the reference's planner table; d_index_fast: the engine's).
+static hipError_t publish_headers(kmx_index* ix)
+{
+    hipError_t e = hipMemcpy(ix->d_index, &ix->h_header, sizeof(KmxIndexDev), hipMemcpyHostToDevice);
+    if (e == hipSuccess && ix->d_index_fast) {
+        KmxIndexDev hf = ix->h_header;
+        if (ix->d_plan_fast) hf.plan = ix->d_plan_fast;
+        e = hipMemcpy(ix->d_index_fast, &hf, sizeof hf, hipMemcpyHostToDevice);
+    }
+    return e;
+}
+// the header a search runs on
+static inline const KmxIndexDev* header_for(const kmx_index* ix, uint32_t flags)
+{
+    static const bool ref_plan_only = getenv("KMX_REFERENCE_PLAN") != nullptr;      // (test / comparison knob)
+    return ((flags & (KMX_SEARCH_KEEP_MASKS | KMX_SEARCH_REFERENCE_PLAN)) || !ix->d_index_fast || ref_plan_only) ? ix->d_index : ix->d_index_fast;
+}
 
 // Uploads flattened element images and everything around them (tail, planner table, header).
 // Shared by kmx_index_build (images fresh from the flatten) and kmx_index_load (images from a file).
@@ -537,6 +558,13 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         if ((st = upload(ix, &h, 1, &d)) != KMX_OK) return bail(st);
         ix->d_index = const_cast<KmxIndexDev*>(d);
         ix->h_header = h;
+        // the engine's own planner table and a second header around it
+        std::vector<KmxPlanEntry> fast = kmx::make_fast_plan_entries(ix->ks, range, sigma);
+        if ((st = upload(ix, fast.data(), fast.size(), &ix->d_plan_fast)) != KMX_OK) return bail(st);
+        if ((st = upload(ix, &h, 1, &d)) != KMX_OK) return bail(st);
+        ix->d_index_fast = const_cast<KmxIndexDev*>(d);
+        const hipError_t pe = publish_headers(ix);
+        if (pe != hipSuccess) { fail(KMX_ERR_HIP, std::string("header: ") + hipGetErrorString(pe)); return bail(KMX_ERR_HIP); }
     }
     *out = ix;
     return KMX_OK;
@@ -578,6 +606,8 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
     h.tail = static_cast<const uint8_t*>(p);
     if (!clone(src->h_header.plan, size_t(h.range) * sizeof(KmxPlanEntry), 16, &p)) return bail(st);
     h.plan = static_cast<const KmxPlanEntry*>(p);
+    if (!clone(src->d_plan_fast, src->d_plan_fast ? size_t(h.range) * sizeof(KmxPlanEntry) : 0, 16, &p)) return bail(st);
+    ix->d_plan_fast = static_cast<const KmxPlanEntry*>(p);
     {
         void* d = nullptr;
         if (hipMalloc(&d, 16 * 8) == hipSuccess) { (void)hipMemset(d, 0, 16 * 8); ix->allocs.push_back(d); h.dbg = static_cast<unsigned long long*>(d); ix->d_dbg = h.dbg; }
@@ -608,6 +638,12 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
         if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("replica header: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
         ix->d_index = static_cast<KmxIndexDev*>(d);
         ix->h_header = h;
+        if (ix->d_plan_fast) {
+            void* d2 = nullptr;
+            e = hipMalloc(&d2, sizeof(KmxIndexDev) + 16);
+            if (e == hipSuccess) { ix->allocs.push_back(d2); ix->d_index_fast = static_cast<KmxIndexDev*>(d2); e = publish_headers(ix); }
+            if (e != hipSuccess) { fail(KMX_ERR_HIP, std::string("replica header: ") + hipGetErrorString(e)); return bail(KMX_ERR_HIP); }
+        }
     }
     *out = ix;
     return KMX_OK;
@@ -691,7 +727,7 @@ static kmx_status add_prefix_levels(kmx_index* ix, const kmx_options& o)
             el.lvl_base[L - 1] = base;
             el.n_levels = uint32_t(L);
             grown = nullptr;
-            he = hipMemcpy(ix->d_index, &h, sizeof h, hipMemcpyHostToDevice);
+            he = publish_headers(ix);
             if (he == hipSuccess) he = hipDeviceSynchronize();
             (void)hipFree(old);
             cleanup();
@@ -1121,23 +1157,47 @@ kmx_status kmx_index_extend_query_size_range(kmx_index* ix, uint32_t new_maximum
 {
     if (!ix || new_maximum == 0 || new_maximum > 65535 * 9u)
         return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_extend_query_size_range: bad argument");
-    for (kmx_index* peer : ix->peers) {
-        const kmx_status ps = kmx_index_extend_query_size_range(peer, new_maximum);
-        if (ps != KMX_OK) return ps;
+    // Every replica gets the new planner table BEFORE any header says so: a step that fails (device memory on replica 2)
+    // leaves all replicas on the old range and the old plan — shards of one batch never classify a length differently.
+    // The caller's current device is left as it was found.
+    int caller_dev = 0;
+    const bool have_dev = hipGetDevice(&caller_dev) == hipSuccess;
+    if (!have_dev) (void)hipGetLastError();
+    auto restore = [&] { if (have_dev) (void)hipSetDevice(caller_dev); };
+    const std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, new_maximum);
+    const std::vector<KmxPlanEntry> fast = kmx::make_fast_plan_entries(ix->ks, new_maximum, ix->sigma);
+    std::vector<kmx_index*> all;
+    all.push_back(ix);
+    for (kmx_index* peer : ix->peers) all.push_back(peer);
+    std::vector<const KmxPlanEntry*> d_plans(all.size(), nullptr), d_fast(all.size(), nullptr);
+    for (size_t i = 0; i < all.size(); ++i) {
+        hipError_t e = hipSetDevice(all[i]->device);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e != hipSuccess) { restore(); return fail(KMX_ERR_HIP, std::string("kmx_index_extend_query_size_range: ") + hipGetErrorString(e)); }
+        kmx_status st = upload(all[i], plan.data(), plan.size(), &d_plans[i]);     // (owned by the replica; unused if we stop here)
+        if (st == KMX_OK && all[i]->d_index_fast) st = upload(all[i], fast.data(), fast.size(), &d_fast[i]);
+        if (st != KMX_OK) { restore(); return st; }
     }
-    HIP_TRY(hipSetDevice(ix->device));
-    HIP_TRY(hipDeviceSynchronize());
-    std::vector<KmxPlanEntry> plan = kmx::make_plan_entries(ix->ks, new_maximum);
-    const KmxPlanEntry* d_plan = nullptr;
-    kmx_status st = upload(ix, plan.data(), plan.size(), &d_plan);
-    if (st != KMX_OK) return st;
-    // patch the two header fields in place (the old table stays allocated until the index is freed)
-    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(ix->d_index) + offsetof(KmxIndexDev, plan), &d_plan, sizeof(d_plan), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(reinterpret_cast<char*>(ix->d_index) + offsetof(KmxIndexDev, range), &new_maximum, sizeof(new_maximum), hipMemcpyHostToDevice));
-    ix->range = new_maximum;
-    ix->h_header.plan = d_plan;
-    ix->h_header.range = new_maximum;
-    return KMX_OK;
+    kmx_status st = KMX_OK;
+    for (size_t i = 0; i < all.size() && st == KMX_OK; ++i) {
+        kmx_index* r = all[i];
+        hipError_t e = hipSetDevice(r->device);
+        // both headers around the new tables (the old tables stay allocated until the index is freed)
+        const KmxIndexDev keep = r->h_header;
+        const KmxPlanEntry* keep_fast = r->d_plan_fast;
+        r->h_header.plan = d_plans[i];
+        r->h_header.range = new_maximum;
+        if (d_fast[i]) r->d_plan_fast = d_fast[i];
+        if (e == hipSuccess) e = publish_headers(r);
+        if (e != hipSuccess) {
+            r->h_header = keep; r->d_plan_fast = keep_fast;
+            st = fail(KMX_ERR_HIP, std::string("kmx_index_extend_query_size_range: ") + hipGetErrorString(e));
+            break;
+        }
+        r->range = new_maximum;
+    }
+    restore();
+    return st;
 }
 
 kmx_status kmx_index_arena_host(const kmx_index* ix, const uint32_t** arena, uint64_t* n_elems)
@@ -1272,7 +1332,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     r->ctr_phase ^= 1u;
     auto* ctr = r->ctr.as<unsigned long long>() + r->ctr_phase * KMX_CTR_COUNT;
     auto* ctr_next = r->ctr.as<unsigned long long>() + (r->ctr_phase ^ 1u) * KMX_CTR_COUNT;
-    const KmxIndexDev* dix = ix->d_index;
+    const KmxIndexDev* dix = header_for(ix, flags);
 
     timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), flags); });
     // speculative scan: already final when the batch holds no STITCH query
@@ -1342,7 +1402,7 @@ static kmx_status search_finish(kmx_result* r)
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
                      r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
     auto* ctr = r->ctr.as<unsigned long long>() + r->ctr_phase * KMX_CTR_COUNT;     // the counter block this search counts into
-    const KmxIndexDev* dix = ix->d_index;
+    const KmxIndexDev* dix = header_for(ix, flags);
     const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
     const uint64_t tile = kmx::fill_tile(fv);
     auto scan_hits = [&] {                                     // (k_validate changed the counts: a full scan)
@@ -1499,7 +1559,7 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
         (void)hipGetLastError();
         unsigned long long* xchg = n_sb > 1 ? r->small_xchg.as<unsigned long long>() : nullptr;
         if (xchg) HIP_TRY(hipMemsetAsync(xchg, 0, KMX_SMALL_BLOCKS * 8, r->own_stream));
-        timed(ix, K_SMALL, r->own_stream, [&] { kmx::launch_small(r->own_stream, ix->d_index, ix->d_arena, mb0, L, n_sb, sargs, uint32_t(nq), xchg, flags); });
+        timed(ix, K_SMALL, r->own_stream, [&] { kmx::launch_small(r->own_stream, header_for(ix, flags), ix->d_arena, mb0, L, n_sb, sargs, uint32_t(nq), xchg, flags); });
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(r->own_stream));
         const KmxSmallHeader* hdrs = reinterpret_cast<const KmxSmallHeader*>(mb0 + L.off_header);
@@ -1587,32 +1647,38 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
     parent->n_hits = parent->n_exact = parent->n_stitch = parent->n_prefix = parent->n_error = parent->n_none = parent->n_mask_words = 0;
     const bool masks = (flags & KMX_SEARCH_KEEP_MASKS) != 0;
     chunk_q = std::max<uint64_t>(chunk_q, 1);
-    for (uint64_t q0 = 0; q0 < nq;) {
-        const uint64_t q1 = std::min(nq, q0 + chunk_q);
-        kmx_status st = search_host_one(ix, qranks, qoff, q0, q1, flags, &parent->worker, true);
-        if (st == KMX_ERR_OUT_OF_MEMORY && chunk_q > 1024) { chunk_q /= 2; (void)hipGetLastError(); continue; }
-        if (st != KMX_OK) return st;
-        kmx_result* w = parent->worker;
+
+    // Chunk i's results leave for the host (device-to-host copies into the worker's page-locked views, then into the part's own
+    // memory) on a helper thread while the calling thread searches chunk i + 1 with the OTHER worker: the PCIe transfer, which
+    // is the long pole of a host-buffer search (55 GB/s against terabytes per second of search), overlaps the search instead
+    // of following it.  A worker is searched into again only after its copy task has been joined.
+    struct CopyTask {
+        std::thread th;
+        kmx_status st = KMX_OK;
+        std::string err;
+        bool running = false;
+    } tasks[2];
+    auto join = [&](int w) -> kmx_status {
+        if (tasks[w].running) { tasks[w].th.join(); tasks[w].running = false; }
+        if (tasks[w].st != KMX_OK) { g_err = tasks[w].err; const kmx_status st = tasks[w].st; tasks[w].st = KMX_OK; return st; }
+        return KMX_OK;
+    };
+    auto copy_out = [&](int wi, kmx_result* w, kmx_result* part, uint64_t cq) {
+        CopyTask& t = tasks[wi];
+        (void)hipSetDevice(ix->device);
         const uint64_t* ho; const uint32_t* pos; const uint8_t* stt; const uint8_t* kd;
-        st = kmx_result_view(w, &ho, &pos, &stt, &kd);
-        if (st == KMX_ERR_OUT_OF_MEMORY && chunk_q > 1024) { chunk_q /= 2; continue; }
-        if (st != KMX_OK) return st;
+        kmx_status st = kmx_result_view(w, &ho, &pos, &stt, &kd);
         const uint64_t* mb = nullptr; const uint64_t* mw = nullptr; const uint32_t* cc = nullptr; const uint64_t* cs = nullptr;
-        if (masks && (st = kmx_result_masks(w, &mb, &mw, &cc, &cs)) != KMX_OK) return st;
-        const uint64_t cq = q1 - q0;
-        auto* part = new kmx_result();
-        parent->parts.push_back(part);
-        parent->part_q0.push_back(q1);
-        part->host_chunk = true; part->small_valid = true; part->host_valid = true; part->host_masks_valid = masks; part->quiesced = true;
-        part->device = ix->device; part->flags = parent->flags; part->nq = cq;
-        part->n_hits = w->n_hits; part->n_exact = w->n_exact; part->n_stitch = w->n_stitch; part->n_prefix = w->n_prefix;
-        part->n_error = w->n_error; part->n_none = w->n_none; part->n_mask_words = w->n_mask_words;
+        if (st == KMX_OK && masks) st = kmx_result_masks(w, &mb, &mw, &cc, &cs);
+        if (st != KMX_OK) { t.st = st; t.err = g_err; return; }
         const bool have_pos = !(flags & KMX_SEARCH_COUNT_ONLY) && w->n_hits;
         if (!part->h_hit_off.ensure_pageable((cq + 1) * 8) || !part->h_status.ensure_pageable(cq + 1) || !part->h_kinds.ensure_pageable(cq + 1) ||
             !part->h_positions.ensure_pageable(have_pos ? w->n_hits * 4 : 4) ||
             (masks && (!part->h_mask_base.ensure_pageable((cq + 1) * 8) || !part->h_cand_count.ensure_pageable((cq + 1) * 4) ||
-                       !part->h_cand_src.ensure_pageable((cq + 1) * 8) || !part->h_mask_words.ensure_pageable((w->n_mask_words + 1) * 8))))
-            return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_search_batch: host allocation for a chunk failed");
+                       !part->h_cand_src.ensure_pageable((cq + 1) * 8) || !part->h_mask_words.ensure_pageable((w->n_mask_words + 1) * 8)))) {
+            t.st = KMX_ERR_OUT_OF_MEMORY; t.err = "kmx_search_batch: host allocation for a chunk failed";
+            return;
+        }
         memcpy(part->h_hit_off.p, ho, (cq + 1) * 8);
         memcpy(part->h_status.p, stt, cq);
         memcpy(part->h_kinds.p, kd, cq);
@@ -1625,11 +1691,44 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
             part->m_base = part->h_mask_base.as<uint64_t>(); part->m_words = part->h_mask_words.as<uint64_t>();
             part->m_ccnt = part->h_cand_count.as<uint32_t>(); part->m_csrc = part->h_cand_src.as<uint64_t>();
         }
+    };
+    auto finish = [&](kmx_status st) -> kmx_status {         // no task outlives the call
+        for (int w = 0; w < 2; ++w) { const kmx_status js = join(w); if (st == KMX_OK) st = js; }
+        return st;
+    };
+    int turn = 0;
+    for (uint64_t q0 = 0; q0 < nq;) {
+        const uint64_t q1 = std::min(nq, q0 + chunk_q);
+        kmx_result*& wr = turn ? parent->worker2 : parent->worker;
+        kmx_status st = join(turn);                          // the worker's previous chunk has left it
+        if (st != KMX_OK) return finish(st);
+        st = search_host_one(ix, qranks, qoff, q0, q1, flags, &wr, true);
+        if (st == KMX_ERR_OUT_OF_MEMORY && chunk_q > 1024) {
+            // smaller chunks, and no second set of device buffers from here on if that is what did not fit
+            chunk_q /= 2; (void)hipGetLastError();
+            const kmx_status js = join(turn ^ 1);
+            if (js != KMX_OK) return finish(js);
+            if (turn && parent->worker2) { kmx_result_free(parent->worker2); parent->worker2 = nullptr; turn = 0; }
+            continue;
+        }
+        if (st != KMX_OK) return finish(st);
+        kmx_result* w = wr;
+        const uint64_t cq = q1 - q0;
+        auto* part = new kmx_result();
+        parent->parts.push_back(part);
+        parent->part_q0.push_back(q1);
+        part->host_chunk = true; part->small_valid = true; part->host_valid = true; part->host_masks_valid = masks; part->quiesced = true;
+        part->device = ix->device; part->flags = parent->flags; part->nq = cq;
+        part->n_hits = w->n_hits; part->n_exact = w->n_exact; part->n_stitch = w->n_stitch; part->n_prefix = w->n_prefix;
+        part->n_error = w->n_error; part->n_none = w->n_none; part->n_mask_words = w->n_mask_words;
         parent->n_hits += part->n_hits; parent->n_exact += part->n_exact; parent->n_stitch += part->n_stitch; parent->n_prefix += part->n_prefix;
         parent->n_error += part->n_error; parent->n_none += part->n_none;
+        tasks[turn].running = true;
+        tasks[turn].th = std::thread(copy_out, turn, w, part, cq);
         q0 = q1;
+        turn ^= 1;
     }
-    return KMX_OK;
+    return finish(KMX_OK);
 }
 
 kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
@@ -1789,8 +1888,11 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
         // the parts of a multi-device result, concatenated in replica order: every device copies straight into its slice
         // of the one host buffer (all links at once), the offsets are rebased on the host
         const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
-        if (!r->h_hit_off.ensure((r->nq + 1) * 8) || !r->h_status.ensure(std::max<uint64_t>(r->nq, 1)) ||
-            !r->h_kinds.ensure(std::max<uint64_t>(r->nq, 1)) || !r->h_positions.ensure(std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
+        // (a chunk-streamed batch is one that did not fit a single pass: its merged view is plain memory — no attempt to
+        // page-lock gigabytes — and every part's copy is given back as soon as it has been appended)
+        auto room = [&](HostBuf& hb, uint64_t bytes) { return r->chunked ? hb.ensure_pageable(bytes) : hb.ensure(bytes); };
+        if (!room(r->h_hit_off, (r->nq + 1) * 8) || !room(r->h_status, std::max<uint64_t>(r->nq, 1)) ||
+            !room(r->h_kinds, std::max<uint64_t>(r->nq, 1)) || !room(r->h_positions, std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
             return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_view: host allocation failed");
         r->v_hit_off = r->h_hit_off.as<uint64_t>();
         r->v_positions = r->h_positions.as<uint32_t>();
@@ -1810,6 +1912,10 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
                 memcpy(r->v_kinds + q0, p->v_kinds, nqp);
                 if (have_pos && p->n_hits) memcpy(r->v_positions + h0, p->v_positions, p->n_hits * 4);
                 h0 += p->n_hits;
+                if (r->chunked) {                                   // the merged view holds it now
+                    p->h_hit_off.release(); p->h_positions.release(); p->h_status.release(); p->h_kinds.release();
+                    p->v_hit_off = nullptr; p->v_positions = nullptr; p->v_status = nullptr; p->v_kinds = nullptr;
+                }
                 continue;
             }
             if (nqp) {
@@ -1943,7 +2049,8 @@ void kmx_result_free(kmx_result* r)
         for (kmx_result* p : r->parts) kmx_result_free(p);     // each part returns to its replica's pool
         r->parts.clear();
         if (r->worker) kmx_result_free(r->worker);
-        r->worker = nullptr;
+        if (r->worker2) kmx_result_free(r->worker2);
+        r->worker = r->worker2 = nullptr;
         r->release();
         delete r;
         return;

@@ -107,6 +107,37 @@ std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uin
     return out;
 }
 
+// The engine's own table for long queries.  The reference plans a query longer than every k on the k that wastes the fewest
+// letters (ceil(q / k) * k - q, kmer_index.hpp:465-473) — for q = 13 on {8, 10, 12} that is k = 8, whose buckets are 256 times
+// as long as those of k = 12 (two buckets of 1526 positions to intersect at 1e8 letters, against two of 6).  Which element
+// answers does not change WHAT is answered — every occurrence of the query, ascending — so for single-k entries with q > k the
+// device table names the LARGEST k <= q instead (shortest buckets), unless either choice could run into the sub-k fan-out guard
+// through its rest (:119-122 via :234: the status must stay the reference's).  Entries of the multi-k scheme, exact lengths and
+// sub-k lengths are the reference's.  Searches that expose the reference's result object (KMX_SEARCH_KEEP_MASKS: candidate run
+// + compressed_bitset of the element the REFERENCE would use) run on the reference's table.
+std::vector<KmxPlanEntry> make_fast_plan_entries(const std::vector<uint32_t>& ks, uint32_t range, uint32_t sigma)
+{
+    std::vector<KmxPlanEntry> out = make_plan_entries(ks, range);
+    if (ks.size() < 2) return out;
+    auto fan_out = [&](uint32_t e) -> bool {             // sigma^e > KMX_SUBK_FANOUT_LIMIT ?
+        unsigned __int128 v = 1;
+        for (uint32_t t = 0; t < e; ++t) { v *= sigma; if (v > KMX_SUBK_FANOUT_LIMIT) return true; }
+        return false;
+    };
+    for (uint32_t q = 1; q < range; ++q) {
+        KmxPlanEntry& e = out[q];
+        if (e.scheme != KMX_SCHEME_SINGLE) continue;
+        const uint32_t k0 = ks[e.elem];
+        if (q <= k0) continue;
+        auto risky = [&](uint32_t k) { const uint32_t r = q % k; return r != 0 && fan_out(k - r); };
+        if (risky(k0)) continue;
+        uint32_t best_k = k0;
+        for (size_t i = 0; i < ks.size(); ++i)
+            if (ks[i] <= q && ks[i] > best_k && !risky(ks[i])) { best_k = ks[i]; e.elem = uint8_t(i); }
+    }
+    return out;
+}
+
 // choose_best_k.hpp:12-60.  Candidates in descending priority (:22-23); every query length gives points to the
 // FIRST candidate that divides it (3 points, :32-36) or misses a multiple by at most 3 (4 - miss points, :38-42);
 // the candidates are then ordered by score (:50-51) and the first n_k returned (:55-57).  The reference sorts

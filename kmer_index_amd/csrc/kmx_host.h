@@ -21,6 +21,9 @@ struct Plan {
 Plan make_plan(const std::vector<uint32_t>& ks, uint32_t range);
 // Device form of the plan for an index holding `ks` (template order).
 std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uint32_t range);
+// ... and the engine's variant of it for searches that need not reproduce the reference's result object: long single-k
+// queries on the largest k that fits them (kmx_host.cpp)
+std::vector<KmxPlanEntry> make_fast_plan_entries(const std::vector<uint32_t>& ks, uint32_t range, uint32_t sigma);
 
 // choose_best_k (choose_best_k.hpp:12-60): which n_k values of k to instantiate for a set of query lengths.
 std::vector<uint32_t> choose_best_k(const uint64_t* lengths, uint64_t n_lengths, uint32_t n_k);

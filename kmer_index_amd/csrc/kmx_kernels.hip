@@ -1006,81 +1006,175 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
 
 #define KMX_VWIDE_SCAN 8
 // k_validate_wide — STITCH queries whose filter bucket has 257 ... KMX_VWIDE entries: more than a 16-lane group of k_validate
-// stages, few enough for the stage of a whole wave.  Same filter as k_validate (:283 binary_search, :544-546 lower_bound),
-// lane = candidate, 64 per round = one compressed_bitset word per ballot, eight rounds searched in lockstep.  Lane = list
-// entry while looking for such queries, then the wave takes them one by one.  Runs behind k_validate<false> and in front
-// of the kernels that check further parts (they read the survivors this one leaves).
+// stages, few enough for the stage of a whole wave.  Candidates and filter bucket are both ASCENDING lists of about the same
+// length here (two long buckets of a small k: 1526 positions per 8-mer at 1e8 letters), so the filter (:283 binary_search,
+// :544-546 lower_bound per candidate) is done as a linear intersection: a lane takes E CONSECUTIVE candidates, finds the
+// first one's place in the staged bucket by one binary search and WALKS from there — the next candidate's lower bound lies a
+// few entries further on (a window of W entries, two or three halving steps, repeated in the rare case the window was too
+// short) — instead of log2(bucket) probe steps for every candidate.  A lane's E verdicts are E consecutive bits of the
+// compressed_bitset (compressed_bitset.hpp:13-14): E / 8 bytes of a byte array in LDS that is read back as 64-bit words.
+// Lane = list entry while looking for such queries, then the wave takes them one by one.  Runs behind k_validate<false> and in
+// front of the kernels that check further parts (they read the survivors this one leaves).
 static_assert(KMX_VWIDE_MIN == KMX_VSTAGE, "k_validate stages filter buckets up to KMX_VSTAGE entries itself");
-__device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ arena, const QueryDesc& d, uint32_t q,
-                                                   uint64_t* __restrict__ mask_words, uint32_t* __restrict__ flat)
+#define KMX_VWIDE_TILE 2048                  // candidates per pass of the wave (64 lanes x up to 32)
+#define KMX_VWIDE_PAD 160                    // the bucket's stage ends in >= 64 entries of 0xFFFFFFFF (the walk's window); one more slot per 32 entries
+template <int E>
+__device__ __forceinline__ uint32_t wide_tile(const uint32_t* __restrict__ cand, uint32_t n_c, const uint32_t* __restrict__ fil, uint32_t pcnt,
+                                              uint32_t P, uint32_t delta, uint32_t wsteps, uint64_t* __restrict__ words,
+                                              uint32_t* __restrict__ sh_out, uint32_t valid, uint32_t* __restrict__ flat)
 {
+    static_assert((E == 8 || E == 16 || E == 32), "a lane's verdicts are whole bytes of the mask; E divides the wave");
     const uint32_t lane = lane_id();
-    const uint32_t c0 = d.c0[q];
-    const uint64_t src = d.src[q] & ~SRC_FLAGS;
-    const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
-    const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
-    uint32_t P = 512;                                                   // pcnt in (256, KMX_VWIDE]; a bucket of exactly P entries is searched
-    while (P < pcnt) P <<= 1;
-    {                                                                   // by membership only, so no pad entry is needed
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // 1. the tile's candidates (+ delta) through LDS: coalesced in, E consecutive ones per lane out (chunks E + 1 words apart:
+    //    no bank conflicts); a slot past the last candidate holds 0, which never moves the walk
+    //    (one pointer per lane, the rounds at immediate offsets: a slot past the bucket reads on into the arena — its allocation
+    //    is padded by more than a tile — and is zeroed)
+    static_assert(KMX_VWIDE_TILE * 4 <= KMX_ARENA_PAD, "a tile of candidates read past the last bucket must stay inside the arena's padding");
+    uint32_t a[E];
+    {
+        const uint32_t* __restrict__ cp = cand + lane;
+#pragma unroll
+        for (int j = 0; j < E; ++j) a[j] = cp[j * KMX_WAVE];
+        // candidate t = 64 j + lane belongs at t + t / E = (lane + lane / E) + j (64 + 64 / E): one address, immediate offsets
+        uint32_t* __restrict__ wp = flat + (lane + lane / E);
+#pragma unroll
+        for (int j = 0; j < E; ++j) wp[j * (KMX_WAVE + KMX_WAVE / E)] = uint32_t(j) * KMX_WAVE + lane < n_c ? a[j] + delta : 0u;
+    }
+    wsync();
+#pragma unroll
+    for (int j = 0; j < E; ++j) a[j] = flat[lane * (E + 1) + j];
+    wsync();
+    // 2. the filter bucket, padded with 0xFFFFFFFF (never a position) to P + 64 entries, in a SKEWED layout: entry i at
+    //    i + i / 32, and the free slot behind every 32 entries repeats the entry after it.  The array stays ascending (a
+    //    lower bound and a membership test do not mind a repeat), and the lanes — whose places in the bucket lie about 32
+    //    entries apart, one chunk of candidates each — meet different LDS banks instead of two.
+    {
         const uint32_t last = pcnt - 1u;
-        const uint32_t* __restrict__ fil = arena + p1src;
-        for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_WAVE) {
+        for (uint32_t t0 = 0; t0 < P + 64; t0 += 4 * KMX_WAVE) {
             const uint32_t t = t0 + 4u * lane;
             u32x4 v = *reinterpret_cast<const u32x4_a4*>(fil + min(t, last));
             v.x = t + 0 < pcnt ? v.x : 0xFFFFFFFFu;
             v.y = t + 1 < pcnt ? v.y : 0xFFFFFFFFu;
             v.z = t + 2 < pcnt ? v.z : 0xFFFFFFFFu;
             v.w = t + 3 < pcnt ? v.w : 0xFFFFFFFFu;
-            *reinterpret_cast<u32x4*>(flat + t) = v;
+            if (t < P + 64) {
+                uint32_t* __restrict__ o = flat + (t + (t >> 5));          // (four entries never straddle a group of 32)
+                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+                if ((t & 31u) == 0 && t) o[-1] = v.x;                     // the repeat in front of a group
+            }
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    wsync();
+    // 3. where the first candidate of a chain belongs (log2 P halving steps over the entries), then the walk over the skewed
+    //    array: a window of eight slots, three halving steps at immediate offsets, once more when a chain's window was too
+    //    short — as C = 4 independent chains per lane (quarters of its E candidates), advanced in lockstep: a chain is one
+    //    dependent LDS read after the other, four of them keep the reads of a lane overlapping
+    const KMX_LDS uint32_t* B = (const KMX_LDS uint32_t*)flat;
+    constexpr int C = 4, LEN = E / C;
+    uint32_t pb[C], tv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) pb[c] = 0;
+    for (uint32_t st = P >> 1; st; st >>= 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) { const uint32_t i = pb[c] + st - 1; tv[c] = B[i + (i >> 5)]; }
+#pragma unroll
+        for (int c = 0; c < C; ++c) pb[c] += tv[c] < a[c * LEN] ? st : 0u;
+    }
+    const KMX_LDS uint32_t* pp[C];                                        // the chains' places in the skewed array
+#pragma unroll
+    for (int c = 0; c < C; ++c) pp[c] = B + (pb[c] + (pb[c] >> 5));
+    uint32_t res = 0;
+#pragma unroll
+    for (int j = 0; j < LEN; ++j) {
+        for (;;) {
+#pragma unroll
+            for (int st = 4; st; st >>= 1) {
+#pragma unroll
+                for (int c = 0; c < C; ++c) tv[c] = pp[c][st - 1];
+#pragma unroll
+                for (int c = 0; c < C; ++c) pp[c] += tv[c] < a[c * LEN + j] ? st : 0;
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) tv[c] = *pp[c];
+            bool more = false;
+#pragma unroll
+            for (int c = 0; c < C; ++c) more |= tv[c] < a[c * LEN + j];
+            if (!__any(more)) break;                                   // (the window was too short for some chain: once more)
+        }
+#pragma unroll
+        for (int c = 0; c < C; ++c) res |= uint32_t(tv[c] == a[c * LEN + j]) << (c * LEN + j);
+    }
+    const uint32_t first = lane * E;
+    const uint32_t live = first < n_c ? min(uint32_t(E), n_c - first) : 0u;
+    res &= live >= 32 ? 0xFFFFFFFFu : (1u << live) - 1u;
+    wsync();                                                           // every read of the bucket is done: the stage takes the verdicts
+    // 4. bit i of the mask = candidate i: the lanes' verdicts as bytes, the words read back
+    {
+        KMX_LDS uint8_t* rb = (KMX_LDS uint8_t*)flat;
+#pragma unroll
+        for (int by = 0; by < E / 8; ++by) rb[lane * (E / 8) + by] = uint8_t(res >> (8 * by));
+        wsync();
+        const uint32_t n_words = (n_c + 63) / 64;
+        if (lane < n_words) words[lane] = ((const KMX_LDS uint64_t*)flat)[lane];
+    }
+    // 5. the survivors, compacted and ascending: what k_fill copies out for this query
+    const uint32_t mine = uint32_t(__popc(res));
+    uint32_t incl = mine;
+#pragma unroll
+    for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o);
+        if (lane >= o) incl += up;
+    }
+    const uint32_t total = uint32_t(__shfl(int(incl), KMX_WAVE - 1));
+    if (sh_out && total) {
+        uint32_t at = valid + incl - mine;
+#pragma unroll
+        for (int j = 0; j < E; ++j)
+            if ((res >> j) & 1u) sh_out[at++] = a[j] - delta;
+    }
+    wsync();                                                           // the stage is the next tile's / query's
+    return valid + total;
+}
+
+__device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ arena, const QueryDesc& d, uint32_t q,
+                                                   uint64_t* __restrict__ mask_words, uint32_t* __restrict__ flat)
+{
+    const uint32_t lane = lane_id();
+    const uint32_t c0 = uint32_t(__builtin_amdgcn_readfirstlane(int(d.c0[q])));
+    const uint64_t src = d.src[q] & ~SRC_FLAGS;
+    const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
+    const uint32_t pcnt = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(p1)))), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
+    uint32_t P = 512;                                                   // pcnt in (256, KMX_VWIDE]
+    while (P < pcnt) P <<= 1;
+    const uint32_t wsteps = 3;                                          // (the walk's window is eight slots)
     uint64_t* __restrict__ words = mask_words + wbase;
     uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + wbase * 64 : nullptr;
     const uint32_t* __restrict__ cand = arena + src;
-    const uint32_t c_last = c0 ? c0 - 1u : 0u;
-    const uint32_t n_rounds = (c0 + KMX_WAVE - 1) / KMX_WAVE;
-    const uint64_t below = (uint64_t(1) << lane) - 1;
+    const uint32_t* __restrict__ fil = arena + p1src;
     uint32_t valid = 0;
-    for (uint32_t it0 = 0; it0 < n_rounds; it0 += KMX_VCH) {
-        const uint32_t nr = min(uint32_t(KMX_VCH), n_rounds - it0);
-        const uint32_t ci0 = it0 * KMX_WAVE + lane;
-        uint32_t x[KMX_VCH];
-#pragma unroll
-        for (int r = 0; r < KMX_VCH; ++r) x[r] = cand[min(ci0 + uint32_t(r) * KMX_WAVE, c_last)] + delta;   // dead slots re-read the last candidate
-        const uint32_t n_live = ci0 < c0 ? min(uint32_t(KMX_VCH), (c0 - ci0 + KMX_WAVE - 1) / KMX_WAVE) : 0u;
-        uint32_t okm;
-        switch ((nr + 1) >> 1) {
-            case 1: okm = staged_members<2>(flat, P, x); break;
-            case 2: okm = staged_members<4>(flat, P, x); break;
-            case 3: okm = staged_members<6>(flat, P, x); break;
-            default: okm = staged_members<8>(flat, P, x); break;
-        }
-        okm &= (1u << n_live) - 1u;
-#pragma unroll
-        for (int r = 0; r < KMX_VCH; ++r) {
-            if (uint32_t(r) >= nr) break;
-            const bool ok = (okm & (1u << r)) != 0;
-            const uint64_t bal = __ballot(ok);                          // 64 candidates = one bitset word (bit i = word i>>6, bit i&63)
-            if (ok && sh_out) sh_out[valid + uint32_t(__popcll(bal & below))] = x[r] - delta;
-            valid += uint32_t(__popcll(bal));
-            if (lane == 0) words[it0 + uint32_t(r)] = bal;
-        }
+    for (uint32_t t0 = 0; t0 < c0; t0 += KMX_VWIDE_TILE) {
+        const uint32_t n_c = min(uint32_t(KMX_VWIDE_TILE), c0 - t0);
+        uint64_t* __restrict__ w = words + t0 / 64;
+        if (n_c <= 512) valid = wide_tile<8>(cand + t0, n_c, fil, pcnt, P, delta, wsteps, w, sh_out, valid, flat);
+        else if (n_c <= 1024) valid = wide_tile<16>(cand + t0, n_c, fil, pcnt, P, delta, wsteps, w, sh_out, valid, flat);
+        else valid = wide_tile<32>(cand + t0, n_c, fil, pcnt, P, delta, wsteps, w, sh_out, valid, flat);
     }
     if (lane == 0) {
         if ((c0 & 63) == 0) words[c0 / 64] = 0;                         // n_bits/64 + 1 words (compressed_bitset.hpp:23)
         d.cnt[q] = valid;
     }
-    __builtin_amdgcn_wave_barrier();                                    // the stage is reused by the wave's next query
 }
 
 #define KMX_VWIDE_BLOCK 256                 // four waves per block: 4 x 8 KB of stage, five blocks per CU
-__global__ __launch_bounds__(KMX_VWIDE_BLOCK) void k_validate_wide(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_stitch,
+__global__ __launch_bounds__(KMX_VWIDE_BLOCK, 4) void k_validate_wide(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_stitch,
                                                                    uint64_t* __restrict__ mask_words)
 {
-    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_VWIDE_BLOCK / KMX_WAVE][KMX_VWIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_VWIDE_BLOCK / KMX_WAVE][KMX_VWIDE + KMX_VWIDE_PAD];
     const uint32_t lane = lane_id();
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_VWIDE_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_VWIDE_BLOCK / KMX_WAVE);

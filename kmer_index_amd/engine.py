@@ -14,7 +14,7 @@ KMX_MAX_KS = 32
 KMX_MAX_DEVICES = 16
 KMX_N_KERNELS = 16
 TABLE_AUTO, TABLE_OPEN, TABLE_DENSE = 0, 1, 2
-SEARCH_DEFAULT, SEARCH_KEEP_MASKS, SEARCH_COUNT_ONLY, SEARCH_ASYNC = 0, 1, 2, 4
+SEARCH_DEFAULT, SEARCH_KEEP_MASKS, SEARCH_COUNT_ONLY, SEARCH_ASYNC, SEARCH_REFERENCE_PLAN = 0, 1, 2, 4, 8
 KIND_NONE, KIND_EXACT, KIND_STITCH, KIND_PREFIX = 0, 1, 2, 3
 Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
 

@@ -46,3 +46,17 @@ def digest(hit_off, positions):
                 w = np.uint64(1099511628211) ** np.arange(a.size, 0, -1, dtype=np.uint64)
                 h = h * (np.uint64(1099511628211) ** np.uint64(a.size)) + np.sum(a * w, dtype=np.uint64)
     return int(h)
+
+
+def inside_envelope(plan, ks, m):
+    """is a query of m letters inside the envelope in which the reference's search() is correct (and the line-by-line
+    restatement, MODE_FAITHFUL, therefore equals ground truth)?  plan = orc.plan(ks): (use_multi, nk_sum).
+    Single k: any m <= k, exact multiples of k, at most two full parts with a rest (kmer_index.hpp:314 breaks the others);
+    multi-k sums: at most two summands (kmer_index.hpp:526, :535)."""
+    multi, nk_sum = plan
+    if m <= 0 or m >= len(nk_sum) or not nk_sum[m]:
+        return True                                   # rejected / unservable lengths: both modes agree on the status
+    if multi[m] and len(ks) > 1:
+        return len(nk_sum[m]) <= 2
+    k = nk_sum[m][0]
+    return m <= k or m % k == 0 or m // k <= 2

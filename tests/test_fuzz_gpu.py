@@ -79,6 +79,15 @@ def _make_queries(rng, sigma, ks, text, count=260):
     return qs
 
 
+def _kinds_of_hits(kinds, hit_off):
+    """Query kinds, with the kind of a query WITHOUT hits left out of the comparison: whether such a query reports NONE (a part
+    of it is absent) or STITCH (every part present, no candidate survives) depends on the element that answered it — the
+    reference's planner under KEEP_MASKS / REFERENCE_PLAN, the largest k that fits otherwise (kmx.h)."""
+    k = kinds.copy()
+    k[np.diff(hit_off) == 0] = 0
+    return k
+
+
 # KMX_FUZZ_SEEDS / KMX_FUZZ_FIRST widen or move the seed window for a longer soak (default: the 96 committed seeds)
 @pytest.mark.parametrize("seed", range(int(os.environ.get("KMX_FUZZ_FIRST", 0)), int(os.environ.get("KMX_FUZZ_FIRST", 0)) + int(os.environ.get("KMX_FUZZ_SEEDS", 96))))
 def test_random_index_and_queries(engine, orc, seed):
@@ -103,14 +112,14 @@ def test_random_index_and_queries(engine, orc, seed):
     # second pass on the same handle (buffer reuse, speculative fill) must agree with itself
     res2 = idx.search(qranks, qoff, result=res)
     ho2, pos2, st2, kd2 = res2.host()
-    assert np.array_equal(ho2, ho) and np.array_equal(pos2, pos) and np.array_equal(kd2, kd), case
+    assert np.array_equal(ho2, ho) and np.array_equal(pos2, pos) and np.array_equal(_kinds_of_hits(kd2, ho2), _kinds_of_hits(kd, ho)), case
     # small slices of the same queries: the latency path (k_small) where the batch suits it, same answers either way
     for size in (1, int(rng.integers(2, 40))):
         b = int(rng.integers(0, len(qs) - size + 1))
         sq, so = pack(qs[b:b + size])
         rs = idx.search(sq, so, flags=flags, result=res)
         h3, p3, s3, k3 = rs.host()
-        assert np.array_equal(s3, st[b:b + size]) and np.array_equal(k3, kd[b:b + size]), case + f" slice {b}+{size}"
+        assert np.array_equal(s3, st[b:b + size]) and np.array_equal(_kinds_of_hits(k3, h3), _kinds_of_hits(kd, ho)[b:b + size]), case + f" slice {b}+{size}"
         assert np.array_equal(h3, ho[b:b + size + 1] - ho[b]) and np.array_equal(p3, pos[int(ho[b]):int(ho[b + size])]), case + f" slice {b}+{size}"
     idx.close()
 

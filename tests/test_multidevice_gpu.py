@@ -181,7 +181,7 @@ def test_batches_too_large_for_one_pass_are_streamed_in_chunks(engine, monkeypat
     assert r4.counts()["nq"] == 0 and r4.host()[0].tolist() == [0]
     # a plain handle turned into the worker of a chunked batch
     monkeypatch.setenv("KMX_HOST_CHUNK", "777")
-    r5 = idx.search(q, off, result=r1)
+    r5 = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS, result=r1)
     assert _same(r5.host(), want) and r5.counts() == c1
     rc.close(); r5.close(); idx.close()
 

@@ -123,7 +123,7 @@ def test_small_batches_equal_the_general_pipeline(engine, sigma, ks, table):
 def test_batches_the_small_kernel_declines_fall_back(engine, orc):
     """More hits than the mailbox holds, long candidate lists, many cross-referenced queries: same answers, general pipeline."""
     text = synth.ranks(3, 2_000_000, 4)
-    idx = engine.Index(text, 4, [4, 6])
+    idx = engine.Index(text, 4, [4, 6], prefix_levels=-1)          # (sub-k slices are merged per query; the reference's planner below)
     idx.stats_enable(True)
     oidx = orc.Index(text, 4, [4, 6])
     cases = {
@@ -138,7 +138,7 @@ def test_batches_the_small_kernel_declines_fall_back(engine, orc):
                                                    [text[s:s + 6] for s in range(3000, 3400)]),
     }
     for name, (q, off) in cases.items():
-        r = idx.search(q, off)
+        r = idx.search(q, off, flags=engine.SEARCH_REFERENCE_PLAN)
         o_off, o_pos, o_st, _ = oidx.search_batch(q, off, mode=orc.MODE_INTENDED)
         h = r.host()
         assert np.array_equal(h[0], o_off) and np.array_equal(h[1], o_pos) and np.array_equal(h[2], o_st.astype(np.uint8)), name
@@ -211,3 +211,39 @@ def test_latency_path_from_concurrent_host_threads(engine):
     assert not errors, errors[:3]
     assert idx.stats()["k_small"]["launches"] >= 8 * 100
     idx.close()
+
+
+@pytest.mark.parametrize("sigma,ks", [(4, [8, 10, 12]), (5, [9]), (20, [4])])
+def test_latency_path_against_the_oracle_directly(engine, orc, sigma, ks):
+    """k_small's results checked against the CPU oracle itself (not against the general pipeline): batches of 1, 7, 64 and
+    256 queries of every kind — exact, sub-k (levels and merged slices), stitched, multi-k, absent, rejected — each one
+    launch of the latency path; inside the envelope of SURVEY 4.3 also against the faithful restatement of the reference."""
+    from tests.helpers import inside_envelope
+    text = synth.ranks(2024 + sigma, 200_000, sigma)
+    kmax = max(ks)
+    lengths = sorted(set([1, 2, max(1, ks[0] - 2), ks[0] - 1, ks[0], ks[0] + 1, kmax, kmax + 3, 2 * ks[0], 2 * kmax + 1, 3 * kmax]))
+    qranks, qoff = make_queries(text, sigma, lengths, 30, seed=11)
+    nq = qoff.size - 1
+    oidx = orc.Index(text, sigma, ks)
+    plan = orc.plan(ks)
+    rng = np.random.default_rng(3)
+    for levels in (0, -1):
+        idx = engine.Index(text, sigma, ks, prefix_levels=levels)
+        idx.stats_enable(True)
+        res = engine.Result()
+        for size in (1, 7, 64, 256, 1, 1):
+            sel = rng.choice(nq, size=size, replace=False)
+            q, off = pack([qranks[int(qoff[i]):int(qoff[i + 1])] for i in sel])
+            before = idx.stats()["k_small"]["launches"]
+            h_off, h_pos, h_st, h_kd = idx.search(q, off, result=res).host()
+            took_small = idx.stats()["k_small"]["launches"] - before
+            o_off, o_pos, o_st, _ = oidx.search_batch(q, off, mode=orc.MODE_INTENDED, n_threads=4)
+            assert np.array_equal(h_st, o_st.astype(np.uint8)) and np.array_equal(h_off, o_off) and np.array_equal(h_pos, o_pos), (levels, size)
+            f_off, f_pos, f_st, _ = oidx.search_batch(q, off, mode=orc.MODE_FAITHFUL, n_threads=4)
+            for j in range(size):
+                if inside_envelope(plan, ks, int(off[j + 1] - off[j])):
+                    assert h_st[j] == f_st[j] and np.array_equal(h_pos[int(h_off[j]):int(h_off[j + 1])], f_pos[int(f_off[j]):int(f_off[j + 1])])
+            if size <= 7:
+                assert took_small == 1, "a handful of queries must take the one-launch path"
+        assert idx.stats()["k_small"]["launches"] >= 4
+        idx.close()
