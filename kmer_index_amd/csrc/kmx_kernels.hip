@@ -30,7 +30,9 @@
 
 #define KMX_BLOCK 256
 #define KMX_WAVE 64
+#ifndef KMX_LOOKUP_ITEMS
 #define KMX_LOOKUP_ITEMS 4     // queries per thread in k_lookup
+#endif
 #define KMX_PSORT_PAIR_CAP 512   // k_prefix_sort_small: slices up to this length are merged pairwise from registers
 #ifndef KMX_PSORT_MULTIWAY_RUNS
 #define KMX_PSORT_MULTIWAY_RUNS 4   // k_prefix_sort_small: multi-way rank pass up to this many runs, bitonic beyond

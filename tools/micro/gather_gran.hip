@@ -35,6 +35,24 @@ __global__ __launch_bounds__(256) void k_gather(const uint32_t* __restrict__ tab
     if (i0 < n) out[i0 / 4] = acc;
 }
 
+// The access pattern of k_fill on a cells layout: G consecutive lanes read the G consecutive words of one cell (one coalesced
+// request of 4 G bytes per cell), four cells per group in flight.
+__global__ __launch_bounds__(256) void k_gather_coop(const uint32_t* __restrict__ table, const uint32_t* __restrict__ idx, uint64_t n,
+                                                     uint32_t stride_words, uint32_t G, uint32_t* __restrict__ out)
+{
+    const uint64_t t = uint64_t(blockIdx.x) * 256 + threadIdx.x;
+    const uint64_t g = t / G, j = t % G;
+    uint32_t acc = 0, v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const uint64_t i = g * 4 + c < n ? g * 4 + c : 0;
+        v[c] = table[uint64_t(idx[i]) * stride_words + j];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc ^= v[c];
+    if (g * 4 < n) out[t % (n / 4 + 1)] = acc;
+}
+
 int main(int argc, char** argv)
 {
     const uint64_t table_bytes = (argc > 1 ? strtoull(argv[1], nullptr, 10) : 4096ull) << 20;   // MiB
@@ -65,6 +83,21 @@ int main(int argc, char** argv)
             printf("table %llu MiB stride %3u mode %d (%3d B/cell): %.4f ms  %.0f M cells/s  useful %.2f TB/s  if-128B-lines %.2f TB/s  if-64B %.2f TB/s\n",
                    (unsigned long long)(table_bytes >> 20), stride, mode, bytes, ms, n / ms / 1e3, n * double(bytes) / ms / 1e9,
                    n * 128.0 / ms / 1e9, n * 64.0 / ms / 1e9);
+        }
+        // cooperative reads: G lanes per cell (modes 10 + log2 G)
+        for (uint32_t G : {8u, 16u, 32u}) {
+            if (G * 4 > stride) continue;
+            const unsigned blocks = unsigned((n / 4 * G + 255) / 256);
+            for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(k_gather_coop, dim3(blocks), dim3(256), 0, 0, d_table, d_idx, n, stride / 4, G, d_out);
+            hipEventRecord(a);
+            const int reps = 5;
+            for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(k_gather_coop, dim3(blocks), dim3(256), 0, 0, d_table, d_idx, n, stride / 4, G, d_out);
+            hipEventRecord(b); hipEventSynchronize(b);
+            float ms; hipEventElapsedTime(&ms, a, b); ms /= reps;
+            const int bytes = int(G * 4);
+            printf("table %llu MiB stride %3u mode %d (%3d B/cell): %.4f ms  %.0f M cells/s  useful %.2f TB/s  if-128B-lines %.2f TB/s  if-64B %.2f TB/s  [%u lanes x 4 B]\n",
+                   (unsigned long long)(table_bytes >> 20), stride, G == 8 ? 13 : G == 16 ? 14 : 15, bytes, ms, n / ms / 1e3, n * double(bytes) / ms / 1e9,
+                   n * 128.0 / ms / 1e9, n * 64.0 / ms / 1e9, G);
         }
     }
     return 0;

@@ -11,7 +11,7 @@ CFG=""
 if [ "$cfg" != "2" ]; then out=${out}_cfg$cfg; CFG="--config $cfg"; fi
 mkdir -p "$out"
 export TMPDIR=/tmp
-BENCH="bench.py $CFG --no-cpu-baseline --no-open-compare --no-two-streams --steps 8 --warmup 2"
+BENCH="bench.py $CFG --no-cpu-baseline --no-open-compare --no-two-streams --no-other-configs --no-host-api --steps 8 --warmup 2"
 timeout -k 10 500 python3 bench.py $CFG > "$out/bench.json" 2> "$out/bench.err"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d "$out/kt" -o kt --output-format csv -- python3 $BENCH > "$out/kt.log" 2>&1
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o fetch --output-format csv -- python3 $BENCH > "$out/fetch.log" 2>&1

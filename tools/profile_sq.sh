@@ -9,7 +9,7 @@ out=gpurun_out/sq_${tag}_cfg$cfg
 mkdir -p "$out"
 export TMPDIR=/tmp
 rocprofv3 -L > "$out/counters_available.txt" 2>&1
-BENCH="bench.py --config $cfg --no-cpu-baseline --no-open-compare --no-two-streams --steps 4 --warmup 1"
+BENCH="bench.py --config $cfg --no-cpu-baseline --no-open-compare --no-two-streams --no-other-configs --no-host-api --steps 4 --warmup 1"
 # any other python command instead of the bench (a probe; its name goes where the config number would):
 #   KMX_SQ_CMD="tools/probe_sweep.py dna4_k=10" bash tools/profile_sq.sh <tag> <name>
 if [ -n "$KMX_SQ_CMD" ]; then BENCH="$KMX_SQ_CMD"; fi

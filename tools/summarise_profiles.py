@@ -37,7 +37,7 @@ def counters(path, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--config", type=int, default=2)
     a = ap.parse_args()
     sfx = "" if a.config == 2 else f"_cfg{a.config}"
@@ -65,6 +65,7 @@ def main():
             "FETCH_SIZE_KiB_mean": round(fk, 1),
             "WRITE_SIZE_KiB_mean": round(wk, 1),
             "fetch_bytes_corrected": int(fk * 1024 * 2),
+            "fetch_bytes_raw": int(fk * 1024),
             "write_bytes": int(wk * 1024),
             "hbm_bytes_per_launch": int(fk * 1024 * 2 + wk * 1024),
             "avg_launch_ms_kernel_trace": round(avg_ns[k][0] / 1e6, 4) if k in avg_ns else None,
@@ -80,7 +81,7 @@ def main():
     fill = max((k for k in kernels if k.startswith("kmx::k_fill<")), key=lambda k: kernels[k]["hbm_bytes_per_launch"] * kernels[k]["launches"])
     out = {
         "source": f"tools/profile_round.sh {a.tag}: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and "
-                  "--kernel-trace --stats, each over `python3 bench.py" + (f" --config {a.config}" if a.config != 2 else "") + " --no-cpu-baseline --no-open-compare --no-two-streams --steps 8 --warmup 2`, MI355X",
+                  "--kernel-trace --stats, each over `python3 bench.py" + (f" --config {a.config}" if a.config != 2 else "") + " --no-cpu-baseline --no-open-compare --no-two-streams --no-other-configs --no-host-api --steps 8 --warmup 2`, MI355X",
         "units": "FETCH_SIZE / WRITE_SIZE are KiB as reported; fetch_bytes_corrected doubles FETCH_SIZE (gfx950 tallies 128-B "
                  "requests at 64 B, MI355X_MICROARCH.md HBM section); calibration in the same run: the largest k_scan_reduce "
                  f"launch reads exactly 4 B x {red_items} items = {4 * red_items} B",
@@ -91,6 +92,12 @@ def main():
             "kernel": fill,
             "hbm_bytes_per_launch": kernels[fill]["hbm_bytes_per_launch"],
             "fetch_bytes_corrected": kernels[fill]["fetch_bytes_corrected"],
+            "fetch_bytes_raw": kernels[fill]["fetch_bytes_raw"],
+            "narrow_read_note": "the x2 correction is calibrated on requests that move a whole 128-byte line (wide streaming reads; 128-byte "
+                                "cells read by 32 lanes: raw 66 B per request, profiles/r03_gather_gran_b.json).  A request for a 32- or 64-byte "
+                                "cell (BASELINE configs 4 / 5: short buckets) is tallied at the same 66 B, and the microbenchmark's rates say such "
+                                "a request moves less than a line (38.8 G 64-byte cells/s = 5.0 TB/s if lines moved, against 3.9 TB/s for 128-byte "
+                                "cells): for kernels whose reads are cell gathers the fabric bytes lie between fetch_bytes_raw and fetch_bytes_corrected",
             "write_bytes": kernels[fill]["write_bytes"],
             "algorithmic_bytes_per_launch": int(bench["roofline"]["algorithmic_bytes_per_launch"]),
             "avg_launch_ms_kernel_trace": kernels[fill]["avg_launch_ms_kernel_trace"],
