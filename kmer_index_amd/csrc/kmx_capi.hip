@@ -656,7 +656,19 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
 // list instead of merging sigma^L buckets.  Optional by nature: a level that does not fit (device memory, 32-bit arena
 // offsets, a key space too large to enumerate) is left out and so are the levels behind it.
 static kmx_status search_finish(kmx_result* r);
+static kmx_status add_prefix_levels_impl(kmx_index* ix, const kmx_options& o);
 static kmx_status add_prefix_levels(kmx_index* ix, const kmx_options& o)
+{
+    // The level searches write their hit lists with ordinary stores: the lists are read right back (into the arena), where the
+    // searches of a user stream them out with non-temporal ones.  (It also keeps the construction's k_fill launches apart from
+    // the searches' in a kernel trace: another instantiation of the kernel.)
+    const kmx::FillVariant keep = ix->fill_variant;
+    ix->fill_variant.nt = false;
+    const kmx_status st = add_prefix_levels_impl(ix, o);
+    ix->fill_variant = keep;
+    return st;
+}
+static kmx_status add_prefix_levels_impl(kmx_index* ix, const kmx_options& o)
 {
     int want = o.prefix_levels;
     if (want == 0) {
@@ -1648,10 +1660,21 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
     const bool masks = (flags & KMX_SEARCH_KEEP_MASKS) != 0;
     chunk_q = std::max<uint64_t>(chunk_q, 1);
 
-    // Chunk i's results leave for the host (device-to-host copies into the worker's page-locked views, then into the part's own
-    // memory) on a helper thread while the calling thread searches chunk i + 1 with the OTHER worker: the PCIe transfer, which
-    // is the long pole of a host-buffer search (55 GB/s against terabytes per second of search), overlaps the search instead
-    // of following it.  A worker is searched into again only after its copy task has been joined.
+    // The PARENT owns the host views of the whole batch (page-locked, grow-only, kept between calls): offsets, statuses and
+    // kinds have known sizes; the positions buffer is sized from the first chunk's hits per query (+ 1/8) and grown if a later
+    // chunk proves that short.  Chunk i's arrays go device-to-host STRAIGHT into their slices of those views (no staging copy,
+    // no per-chunk host memory) on a helper thread, while the calling thread searches chunk i + 1 with the OTHER worker: the
+    // PCIe transfer — the long pole of a host-buffer search, 55 GB/s against terabytes per second of search — overlaps the
+    // search instead of following it.  A worker is searched into again only after its copy task has been joined.
+    const bool want_pos = !(flags & KMX_SEARCH_COUNT_ONLY);
+    const uint64_t nq1 = std::max<uint64_t>(nq, 1);
+    if (!parent->h_hit_off.ensure((nq + 1) * 8) || !parent->h_status.ensure(nq1) || !parent->h_kinds.ensure(nq1))
+        return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_search_batch: host allocation failed");
+    parent->v_hit_off = parent->h_hit_off.as<uint64_t>();
+    parent->v_status = parent->h_status.as<uint8_t>();
+    parent->v_kinds = parent->h_kinds.as<uint8_t>();
+    parent->v_positions = parent->h_positions.as<uint32_t>();
+    parent->v_hit_off[0] = 0;
     struct CopyTask {
         std::thread th;
         kmx_status st = KMX_OK;
@@ -1663,40 +1686,40 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
         if (tasks[w].st != KMX_OK) { g_err = tasks[w].err; const kmx_status st = tasks[w].st; tasks[w].st = KMX_OK; return st; }
         return KMX_OK;
     };
-    auto copy_out = [&](int wi, kmx_result* w, kmx_result* part, uint64_t cq) {
+    auto finish = [&](kmx_status st) -> kmx_status {         // no task outlives the call
+        for (int w = 0; w < 2; ++w) { const kmx_status js = join(w); if (st == KMX_OK) st = js; }
+        return st;
+    };
+    auto copy_out = [&](int wi, kmx_result* w, kmx_result* part, uint64_t q0, uint64_t cq, uint64_t h0) {
         CopyTask& t = tasks[wi];
-        (void)hipSetDevice(ix->device);
-        const uint64_t* ho; const uint32_t* pos; const uint8_t* stt; const uint8_t* kd;
-        kmx_status st = kmx_result_view(w, &ho, &pos, &stt, &kd);
-        const uint64_t* mb = nullptr; const uint64_t* mw = nullptr; const uint32_t* cc = nullptr; const uint64_t* cs = nullptr;
-        if (st == KMX_OK && masks) st = kmx_result_masks(w, &mb, &mw, &cc, &cs);
-        if (st != KMX_OK) { t.st = st; t.err = g_err; return; }
-        const bool have_pos = !(flags & KMX_SEARCH_COUNT_ONLY) && w->n_hits;
-        if (!part->h_hit_off.ensure_pageable((cq + 1) * 8) || !part->h_status.ensure_pageable(cq + 1) || !part->h_kinds.ensure_pageable(cq + 1) ||
-            !part->h_positions.ensure_pageable(have_pos ? w->n_hits * 4 : 4) ||
-            (masks && (!part->h_mask_base.ensure_pageable((cq + 1) * 8) || !part->h_cand_count.ensure_pageable((cq + 1) * 4) ||
-                       !part->h_cand_src.ensure_pageable((cq + 1) * 8) || !part->h_mask_words.ensure_pageable((w->n_mask_words + 1) * 8)))) {
-            t.st = KMX_ERR_OUT_OF_MEMORY; t.err = "kmx_search_batch: host allocation for a chunk failed";
-            return;
-        }
-        memcpy(part->h_hit_off.p, ho, (cq + 1) * 8);
-        memcpy(part->h_status.p, stt, cq);
-        memcpy(part->h_kinds.p, kd, cq);
-        if (have_pos) memcpy(part->h_positions.p, pos, w->n_hits * 4);
-        part->v_hit_off = part->h_hit_off.as<uint64_t>(); part->v_positions = part->h_positions.as<uint32_t>();
-        part->v_status = part->h_status.as<uint8_t>(); part->v_kinds = part->h_kinds.as<uint8_t>();
+        hipError_t e = hipSetDevice(ix->device);
+        hipStream_t cs = w->stream;
+        // (search_host_one left the worker complete: counters read, every kernel of the chunk done)
+        if (e == hipSuccess && cq) e = hipMemcpyAsync(parent->v_hit_off + q0 + 1, w->hit_off.as<uint64_t>() + 1, cq * 8, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess && cq) e = hipMemcpyAsync(parent->v_status + q0, w->status.p, cq, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess && cq) e = hipMemcpyAsync(parent->v_kinds + q0, w->kind.p, cq, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess && want_pos && w->n_hits) e = hipMemcpyAsync(parent->v_positions + h0, w->out.p, w->n_hits * 4, hipMemcpyDeviceToHost, cs);
+        if (e == hipSuccess) e = hipStreamSynchronize(cs);
+        if (e != hipSuccess) { t.st = KMX_ERR_HIP; t.err = std::string("kmx_search_batch: chunk copy: ") + hipGetErrorString(e); return; }
+        if (h0)
+            for (uint64_t q = q0 + 1; q <= q0 + cq; ++q) parent->v_hit_off[q] += h0;
         if (masks) {
-            memcpy(part->h_mask_base.p, mb, cq * 8); memcpy(part->h_cand_count.p, cc, cq * 4); memcpy(part->h_cand_src.p, cs, cq * 8);
+            const uint64_t* mb = nullptr; const uint64_t* mw = nullptr; const uint32_t* cc = nullptr; const uint64_t* cs2 = nullptr;
+            const kmx_status st = kmx_result_masks(w, &mb, &mw, &cc, &cs2);
+            if (st != KMX_OK) { t.st = st; t.err = g_err; return; }
+            if (!part->h_mask_base.ensure_pageable((cq + 1) * 8) || !part->h_cand_count.ensure_pageable((cq + 1) * 4) ||
+                !part->h_cand_src.ensure_pageable((cq + 1) * 8) || !part->h_mask_words.ensure_pageable((w->n_mask_words + 1) * 8)) {
+                t.st = KMX_ERR_OUT_OF_MEMORY; t.err = "kmx_search_batch: host allocation for a chunk's masks failed";
+                return;
+            }
+            memcpy(part->h_mask_base.p, mb, cq * 8); memcpy(part->h_cand_count.p, cc, cq * 4); memcpy(part->h_cand_src.p, cs2, cq * 8);
             if (w->n_mask_words) memcpy(part->h_mask_words.p, mw, w->n_mask_words * 8);
             part->m_base = part->h_mask_base.as<uint64_t>(); part->m_words = part->h_mask_words.as<uint64_t>();
             part->m_ccnt = part->h_cand_count.as<uint32_t>(); part->m_csrc = part->h_cand_src.as<uint64_t>();
         }
     };
-    auto finish = [&](kmx_status st) -> kmx_status {         // no task outlives the call
-        for (int w = 0; w < 2; ++w) { const kmx_status js = join(w); if (st == KMX_OK) st = js; }
-        return st;
-    };
     int turn = 0;
+    uint64_t h0 = 0;                                          // hits of the chunks in front
     for (uint64_t q0 = 0; q0 < nq;) {
         const uint64_t q1 = std::min(nq, q0 + chunk_q);
         kmx_result*& wr = turn ? parent->worker2 : parent->worker;
@@ -1713,22 +1736,72 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
         }
         if (st != KMX_OK) return finish(st);
         kmx_result* w = wr;
+        if (w->small_valid) {
+            // (a chunk small enough for the one-launch latency path leaves nothing in HBM: its views are host memory already)
+            const uint64_t* ho; const uint32_t* pos; const uint8_t* stt; const uint8_t* kd;
+            if ((st = kmx_result_view(w, &ho, &pos, &stt, &kd)) != KMX_OK) return finish(st);
+        }
         const uint64_t cq = q1 - q0;
+        if (want_pos && (h0 + w->n_hits) * 4 > parent->h_positions.cap) {
+            // the positions view: room for this chunk and, by its hits per query so far, for the rest of the batch
+            if ((st = finish(KMX_OK)) != KMX_OK) return st;  // (copies into the old buffer are done)
+            const uint64_t sofar = h0 + w->n_hits;
+            const uint64_t guess = q1 < nq ? sofar + (sofar / std::max<uint64_t>(q1, 1) + 1) * (nq - q1) * 9 / 8 : sofar;
+            HostBuf bigger;
+            if (!bigger.ensure(std::max<uint64_t>(guess, 1) * 4)) return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_search_batch: host allocation for the hit lists failed");
+            if (h0) memcpy(bigger.p, parent->h_positions.p, h0 * 4);
+            parent->h_positions.release();
+            parent->h_positions = bigger;
+            bigger.p = nullptr; bigger.cap = 0;               // (moved)
+            parent->v_positions = parent->h_positions.as<uint32_t>();
+        }
         auto* part = new kmx_result();
         parent->parts.push_back(part);
         parent->part_q0.push_back(q1);
-        part->host_chunk = true; part->small_valid = true; part->host_valid = true; part->host_masks_valid = masks; part->quiesced = true;
+        part->host_chunk = true; part->host_valid = true; part->host_masks_valid = masks; part->quiesced = true;
         part->device = ix->device; part->flags = parent->flags; part->nq = cq;
         part->n_hits = w->n_hits; part->n_exact = w->n_exact; part->n_stitch = w->n_stitch; part->n_prefix = w->n_prefix;
         part->n_error = w->n_error; part->n_none = w->n_none; part->n_mask_words = w->n_mask_words;
         parent->n_hits += part->n_hits; parent->n_exact += part->n_exact; parent->n_stitch += part->n_stitch; parent->n_prefix += part->n_prefix;
         parent->n_error += part->n_error; parent->n_none += part->n_none;
-        tasks[turn].running = true;
-        tasks[turn].th = std::thread(copy_out, turn, w, part, cq);
+        if (w->small_valid) {                                // host to host, here and now
+            memcpy(parent->v_hit_off + q0 + 1, w->v_hit_off + 1, cq * 8);
+            memcpy(parent->v_status + q0, w->v_status, cq);
+            memcpy(parent->v_kinds + q0, w->v_kinds, cq);
+            if (want_pos && w->n_hits) memcpy(parent->v_positions + h0, w->v_positions, w->n_hits * 4);
+            if (h0)
+                for (uint64_t q = q0 + 1; q <= q1; ++q) parent->v_hit_off[q] += h0;
+            if (masks) {
+                tasks[turn].running = true;
+                tasks[turn].th = std::thread([&, turn, w, part, q0, cq] {
+                    // (masks only: reuse the copy task with nothing else left to move)
+                    CopyTask& t = tasks[turn];
+                    const uint64_t* mb = nullptr; const uint64_t* mw = nullptr; const uint32_t* cc = nullptr; const uint64_t* cs2 = nullptr;
+                    const kmx_status ms = kmx_result_masks(w, &mb, &mw, &cc, &cs2);
+                    if (ms != KMX_OK) { t.st = ms; t.err = g_err; return; }
+                    if (!part->h_mask_base.ensure_pageable((cq + 1) * 8) || !part->h_cand_count.ensure_pageable((cq + 1) * 4) ||
+                        !part->h_cand_src.ensure_pageable((cq + 1) * 8) || !part->h_mask_words.ensure_pageable((w->n_mask_words + 1) * 8)) {
+                        t.st = KMX_ERR_OUT_OF_MEMORY; t.err = "kmx_search_batch: host allocation for a chunk's masks failed"; return;
+                    }
+                    memcpy(part->h_mask_base.p, mb, cq * 8); memcpy(part->h_cand_count.p, cc, cq * 4); memcpy(part->h_cand_src.p, cs2, cq * 8);
+                    if (w->n_mask_words) memcpy(part->h_mask_words.p, mw, w->n_mask_words * 8);
+                    part->m_base = part->h_mask_base.as<uint64_t>(); part->m_words = part->h_mask_words.as<uint64_t>();
+                    part->m_ccnt = part->h_cand_count.as<uint32_t>(); part->m_csrc = part->h_cand_src.as<uint64_t>();
+                    (void)q0;
+                });
+            }
+        } else {
+            tasks[turn].running = true;
+            tasks[turn].th = std::thread(copy_out, turn, w, part, q0, cq, h0);
+        }
+        h0 += w->n_hits;
         q0 = q1;
         turn ^= 1;
     }
-    return finish(KMX_OK);
+    const kmx_status fs = finish(KMX_OK);
+    if (fs != KMX_OK) return fs;
+    parent->host_valid = true;                               // the merged views ARE the chunks' destination
+    return KMX_OK;
 }
 
 kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq,
@@ -1888,11 +1961,9 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
         // the parts of a multi-device result, concatenated in replica order: every device copies straight into its slice
         // of the one host buffer (all links at once), the offsets are rebased on the host
         const bool have_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
-        // (a chunk-streamed batch is one that did not fit a single pass: its merged view is plain memory — no attempt to
-        // page-lock gigabytes — and every part's copy is given back as soon as it has been appended)
-        auto room = [&](HostBuf& hb, uint64_t bytes) { return r->chunked ? hb.ensure_pageable(bytes) : hb.ensure(bytes); };
-        if (!room(r->h_hit_off, (r->nq + 1) * 8) || !room(r->h_status, std::max<uint64_t>(r->nq, 1)) ||
-            !room(r->h_kinds, std::max<uint64_t>(r->nq, 1)) || !room(r->h_positions, std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
+        // (a chunk-streamed batch never gets here: its chunks were copied into the parent's views as they were searched)
+        if (!r->h_hit_off.ensure((r->nq + 1) * 8) || !r->h_status.ensure(std::max<uint64_t>(r->nq, 1)) ||
+            !r->h_kinds.ensure(std::max<uint64_t>(r->nq, 1)) || !r->h_positions.ensure(std::max<uint64_t>(have_pos ? r->n_hits * 4 : 0, 4)))
             return fail(KMX_ERR_OUT_OF_MEMORY, "kmx_result_view: host allocation failed");
         r->v_hit_off = r->h_hit_off.as<uint64_t>();
         r->v_positions = r->h_positions.as<uint32_t>();
@@ -1912,10 +1983,6 @@ kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32
                 memcpy(r->v_kinds + q0, p->v_kinds, nqp);
                 if (have_pos && p->n_hits) memcpy(r->v_positions + h0, p->v_positions, p->n_hits * 4);
                 h0 += p->n_hits;
-                if (r->chunked) {                                   // the merged view holds it now
-                    p->h_hit_off.release(); p->h_positions.release(); p->h_status.release(); p->h_kinds.release();
-                    p->v_hit_off = nullptr; p->v_positions = nullptr; p->v_status = nullptr; p->v_kinds = nullptr;
-                }
                 continue;
             }
             if (nqp) {
