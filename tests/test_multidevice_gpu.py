@@ -79,6 +79,47 @@ def test_n_replicas_return_the_single_device_result_byte_for_byte(engine, table)
     one.close()
 
 
+def test_replicas_on_distinct_physical_devices(engine):
+    """The same contract with every replica on a GPU of its own (hipMemcpyPeer between devices, one host thread and one stream
+    per device, per-part device views that live on different devices) — what the [0, 0] replica lists of the other tests
+    cannot show.  SKIPPED, not faked, on a box with one GPU: until a multi-GPU box has run it, cross-device correctness of
+    the in-process replicas is unpinned (README)."""
+    import torch
+    n = torch.cuda.device_count()
+    if n < 2:
+        pytest.skip("needs two visible GPUs")
+    devs = list(range(min(n, 4)))
+    text = synth.ranks(1003, 400_000, 4)
+    ks = [8, 10, 12]
+    q, off = make_queries(text, 4, [3, 6, 8, 9, 10, 12, 13, 20, 22, 24, 31, 36], 300, seed=5)
+    one = engine.Index(text, 4, ks, device=0)
+    want = one.search(q, off).host()
+    many = engine.Index(text, 4, ks, devices=devs)
+    assert many.devices() == devs
+    rn = many.search(q, off)
+    assert rn.n_parts() == len(devs) and _same(rn.host(), want)
+    for p in range(rn.n_parts()):
+        dev, qb, qe, d_off, d_pos, d_st = rn.part_device_ptrs(p)
+        assert dev == devs[p]
+        with torch.cuda.device(dev):                       # the part's arrays really live on that device
+            class _Arr:
+                def __init__(self, ptr, cnt, typestr):
+                    self.__cuda_array_interface__ = {"shape": (int(cnt),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+            t_off = torch.as_tensor(_Arr(d_off, qe - qb + 1, "<i8"), device=f"cuda:{dev}").cpu().numpy().astype(np.uint64)
+        assert np.array_equal(t_off - t_off[0], want[0][qb:qe + 1] - want[0][qb])
+    # the device form is served by the replica that lives where the queries are
+    d = devs[-1]
+    tq = torch.from_numpy(q).to(f"cuda:{d}")
+    to = torch.from_numpy(off.view(np.int64)).to(f"cuda:{d}")
+    with torch.cuda.device(d):
+        r = many.search_device(tq.data_ptr(), to.data_ptr(), off.size - 1, stream=torch.cuda.current_stream().cuda_stream)
+        assert _same(r.host(), want)
+    # the planner range moves on every replica or on none
+    many.extend_query_size_range(20_000)
+    assert _same(many.search(q, off, result=rn).host(), want)
+    rn.close(); r.close(); many.close(); one.close()
+
+
 def test_fewer_queries_than_replicas_and_empty_batches(engine):
     text = synth.ranks(5, 50_000, 4)
     many = engine.Index(text, 4, [6], devices=[0, 0, 0])
