@@ -177,6 +177,13 @@ kmx_status kmx_index_extend_query_size_range(kmx_index* index, uint32_t new_maxi
 kmx_status kmx_plan(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint8_t* use_multi,
                     uint32_t* nk_off, uint32_t* nk_flat, uint64_t cap, uint64_t* n_flat);
 
+/* The ENGINE's choice of element per query length (see KMX_SEARCH_REFERENCE_PLAN): k_used[q], q < range, is the k whose
+ * element answers a query of q letters that the reference plans on ONE k — the reference's k for q <= k, exact multiples that
+ * have no larger k to go to, and lengths whose rest could reach the sub-k fan-out guard on either choice; otherwise the largest
+ * k of the index that fits q.  0 for lengths the reference answers with its multi-k scheme (their summands are kmx_plan's) and
+ * for q == 0.  Pure host code; what a search without KMX_SEARCH_KEEP_MASKS / KMX_SEARCH_REFERENCE_PLAN runs on. */
+kmx_status kmx_plan_engine(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint32_t sigma, uint32_t* k_used);
+
 /* choose_best_k (choose_best_k.hpp:12-60): the n_k (<= 10) values of k the reference's heuristic recommends for a
  * set of query lengths — candidates {29,27,25,23,21,19,17,13,11,10}, 3 points for a length the candidate divides,
  * 4 - miss points for a miss of at most 3, best scores first.  Pure host code. */

@@ -868,6 +868,17 @@ kmx_status kmx_plan(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint8_t* 
     return KMX_OK;
 }
 
+kmx_status kmx_plan_engine(const uint32_t* ks, uint32_t n_ks, uint32_t range, uint32_t sigma, uint32_t* k_used)
+{
+    if (!ks || !k_used || n_ks == 0 || n_ks > KMX_MAX_KS || range == 0 || sigma < 2) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_plan_engine: bad ks / range / sigma");
+    for (uint32_t i = 0; i < n_ks; ++i)
+        if (ks[i] == 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_plan_engine: k must be > 0");
+    const std::vector<uint32_t> v(ks, ks + n_ks);
+    const std::vector<KmxPlanEntry> fast = kmx::make_fast_plan_entries(v, range, sigma);
+    for (uint32_t q = 0; q < range; ++q) k_used[q] = (q && fast[q].scheme == KMX_SCHEME_SINGLE) ? v[fast[q].elem] : 0u;
+    return KMX_OK;
+}
+
 kmx_status kmx_index_build(const uint8_t* ranks, uint64_t n, uint32_t sigma, const uint32_t* ks, uint32_t n_ks,
                            const kmx_options* opts, kmx_index** out)
 {

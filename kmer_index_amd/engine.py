@@ -20,7 +20,7 @@ Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
 
 # every symbol include/kmx.h declares
 EXPORTS = [
-    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_choose_best_k", "kmx_plan", "kmx_fast_pow",
+    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_choose_best_k", "kmx_plan", "kmx_plan_engine", "kmx_fast_pow",
     "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
@@ -80,6 +80,8 @@ def lib():
         L.kmx_choose_best_k.restype = C.c_int
         L.kmx_choose_best_k.argtypes = [vp, u64, u32, vp]
         L.kmx_plan.restype = C.c_int
+        L.kmx_plan_engine.restype = C.c_int
+        L.kmx_plan_engine.argtypes = [vp, u32, u32, u32, vp]
         L.kmx_plan.argtypes = [vp, u32, u32, vp, vp, vp, u64, P(u64)]
         L.kmx_fast_pow.restype = u64
         L.kmx_fast_pow.argtypes = [u64, C.c_uint8]
@@ -158,6 +160,14 @@ def plan(ks, rng=10000):
     flat = np.zeros(max(n.value, 1), np.uint32)
     _check(lib().kmx_plan(ks.ctypes.data, ks.size, rng, multi.ctypes.data, off.ctypes.data, flat.ctypes.data, n.value, C.byref(n)))
     return multi.astype(bool), [flat[off[q]:off[q + 1]].tolist() for q in range(rng)]
+
+
+def plan_engine(ks, sigma, rng=10000):
+    """k_used[rng] from kmx_plan_engine: the k whose element the ENGINE answers a single-k length from (0: multi-k scheme)."""
+    ks = np.ascontiguousarray(ks, np.uint32)
+    out = np.zeros(rng, np.uint32)
+    _check(lib().kmx_plan_engine(ks.ctypes.data, ks.size, rng, int(sigma), out.ctypes.data))
+    return out
 
 
 def _view(ptr, n, dtype):

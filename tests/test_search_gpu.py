@@ -95,6 +95,33 @@ def test_outside_the_envelope_the_engine_follows_ground_truth_not_the_reference(
         idx.close()
 
 
+@pytest.mark.parametrize("sigma,ks", [(4, [8, 10, 12]), (20, [3, 5]), (4, [6, 9])])
+def test_engine_plan_and_reference_plan_return_the_same_lists(engine, orc, sigma, ks):
+    """A single-k query longer than its k is answered from the largest k that fits (kmx_plan_engine) unless the call asks for
+    the reference's planner (KMX_SEARCH_REFERENCE_PLAN, implied by KEEP_MASKS): statuses, offsets and position lists are the
+    same either way and equal the oracle's; kinds differ at most between NONE and STITCH for queries without hits."""
+    text = synth.ranks(77 + sigma, 500_000, sigma)
+    used = engine.plan_engine(ks, sigma, 200)
+    multi, nk_sum = engine.plan(ks, 200)
+    lengths = [m for m in range(max(ks) + 1, 70) if not (multi[m] and len(ks) > 1) and used[m] != nk_sum[m][0]][:14]
+    assert len(lengths) >= 5, "the case must hold lengths on which the two planners disagree"
+    lengths += [max(ks), 2 * max(ks), min(ks) - 1]
+    qranks, qoff = make_queries(text, sigma, lengths, 60, seed=21)
+    idx = engine.Index(text, sigma, ks)
+    a = idx.search(qranks, qoff).host()
+    b = idx.search(qranks, qoff, flags=engine.SEARCH_REFERENCE_PLAN).host()
+    c = idx.search(qranks, qoff, flags=engine.SEARCH_KEEP_MASKS).host()
+    o_off, o_pos, o_st, _ = orc.Index(text, sigma, ks).search_batch(qranks, qoff, n_threads=4)
+    for r in (a, b, c):
+        assert np.array_equal(r[2], o_st.astype(np.uint8)) and np.array_equal(r[0], o_off) and np.array_equal(r[1], o_pos)
+    assert np.array_equal(b[3], c[3])
+    hits = np.diff(a[0]) > 0
+    assert np.array_equal(a[3][hits], b[3][hits])
+    differ = a[3] != b[3]
+    assert set(a[3][differ].tolist()) | set(b[3][differ].tolist()) <= {engine.KIND_NONE, engine.KIND_STITCH}
+    idx.close()
+
+
 def test_exact_k10_large_batch(engine, orc):
     """The headline shape, down-scaled: uniform random 10-mers, every one present many times."""
     text = synth.ranks(1002, 2_000_000, 4)
