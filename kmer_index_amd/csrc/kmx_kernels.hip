@@ -14,8 +14,10 @@
 //   k_partition     first query of every output tile
 //   k_fill          output-centric copy of bucket runs -> to_vector() lists
 //  [k_compact]      STITCH fallback without a survivor buffer: mask-word decode, popcount prefix compaction
-//  [k_merge_pass*]  PREFIX: merge of the per-key runs into one ascending list (the
-//                   std::sort of kmer_index_result.hpp:258)
+//  [k_prefix_*]     PREFIX slices of several runs: merged into one ascending list (the std::sort of
+//                   kmer_index_result.hpp:258) — k_prefix_sort_small / k_prefix_merge_small / k_prefix_sort_block /
+//                   k_prefix_merge_pass by slice length; slices of one run (prefix levels) need none of them
+//  [k_validate_wide / k_validate_more_thread]  long filter buckets (linear intersection) / few further parts per query
 //
 // All arithmetic is unsigned integer; no MFMA.  The kernels are HBM / latency
 // bound: see DESIGN.md for bytes per unit and the roofline of each.
@@ -1022,7 +1024,7 @@ static_assert(KMX_VWIDE_MIN == KMX_VSTAGE, "k_validate stages filter buckets up 
 #define KMX_VWIDE_PAD 160                    // the bucket's stage ends in >= 64 entries of 0xFFFFFFFF (the walk's window); one more slot per 32 entries
 template <int E>
 __device__ __forceinline__ uint32_t wide_tile(const uint32_t* __restrict__ cand, uint32_t n_c, const uint32_t* __restrict__ fil, uint32_t pcnt,
-                                              uint32_t P, uint32_t delta, uint32_t wsteps, uint64_t* __restrict__ words,
+                                              uint32_t P, uint32_t delta, uint64_t* __restrict__ words,
                                               uint32_t* __restrict__ sh_out, uint32_t valid, uint32_t* __restrict__ flat)
 {
     static_assert((E == 8 || E == 16 || E == 32), "a lane's verdicts are whole bytes of the mask; E divides the wave");
@@ -1153,7 +1155,6 @@ __device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ 
     const uint32_t pcnt = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(p1)))), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
     uint32_t P = 512;                                                   // pcnt in (256, KMX_VWIDE]
     while (P < pcnt) P <<= 1;
-    const uint32_t wsteps = 3;                                          // (the walk's window is eight slots)
     uint64_t* __restrict__ words = mask_words + wbase;
     uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + wbase * 64 : nullptr;
     const uint32_t* __restrict__ cand = arena + src;
@@ -1162,9 +1163,9 @@ __device__ __forceinline__ void validate_wide_wave(const uint32_t* __restrict__ 
     for (uint32_t t0 = 0; t0 < c0; t0 += KMX_VWIDE_TILE) {
         const uint32_t n_c = min(uint32_t(KMX_VWIDE_TILE), c0 - t0);
         uint64_t* __restrict__ w = words + t0 / 64;
-        if (n_c <= 512) valid = wide_tile<8>(cand + t0, n_c, fil, pcnt, P, delta, wsteps, w, sh_out, valid, flat);
-        else if (n_c <= 1024) valid = wide_tile<16>(cand + t0, n_c, fil, pcnt, P, delta, wsteps, w, sh_out, valid, flat);
-        else valid = wide_tile<32>(cand + t0, n_c, fil, pcnt, P, delta, wsteps, w, sh_out, valid, flat);
+        if (n_c <= 512) valid = wide_tile<8>(cand + t0, n_c, fil, pcnt, P, delta, w, sh_out, valid, flat);
+        else if (n_c <= 1024) valid = wide_tile<16>(cand + t0, n_c, fil, pcnt, P, delta, w, sh_out, valid, flat);
+        else valid = wide_tile<32>(cand + t0, n_c, fil, pcnt, P, delta, w, sh_out, valid, flat);
     }
     if (lane == 0) {
         if ((c0 & 63) == 0) words[c0 / 64] = 0;                         // n_bits/64 + 1 words (compressed_bitset.hpp:23)
@@ -2601,14 +2602,14 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
 }
 
 // ---------------------------------------------------------------------------
-// k_merge_pass — PREFIX queries: the slice copied by k_fill is the concatenation
-// of the ascending runs of consecutive keys; pass t merges neighbouring groups
-// of 2^t runs by ranking every element in its sibling group (no two runs share a
-// position, so ranks are unique).  ceil(log2(max runs)) passes sort every slice,
-// which is the std::sort of kmer_index_result.hpp:258.
-// Element space = concatenation of the PREFIX slices (poff from a scan over
-// prefix_list); buffers alternate between `out` (addressed by hit_off) and `tmp`
-// (addressed by poff).
+// PREFIX queries whose slice is SEVERAL ascending runs (a slice that is one run — a prefix level's list, the only key of
+// a range — is in order as k_fill copies it and appears on no work list).  By slice length:
+//   <= 2048            one wave per query: k_prefix_sort_small (<= 4 runs / 512 positions from registers; many short runs
+//                      by a bitonic network) or k_prefix_merge_small (merge_runs_lds)
+//   <= 8192 / <= 32768 one 256- / 1024-thread block per query: k_prefix_sort_block (merge_runs_lds per chunk)
+//   beyond             chunks of 32768 by k_prefix_sort_block, then k_prefix_merge_pass, ceil(log2 chunks) times
+// All of them read the slice where it lies in the arena and write `out`; k_fill leaves those slots alone.
+// k_prefix_len: tiles of the slices that need merge passes (0 for the others).
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t n_prefix,
                                                           uint32_t* __restrict__ plen)
