@@ -1008,173 +1008,6 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
     }
 }
 
-// ---------------------------------------------------------------------------
-// k_validate_walk — the filter of k_validate<false> as a LINEAR INTERSECTION.  Candidates and filter bucket are both
-// ascending, so membership of every candidate need not be a search of its own (:283 binary_search, :544-546 lower_bound per
-// candidate): a lane takes KMX_VW_E CONSECUTIVE candidates of its query (16 lanes x 8 = 128 per pass = two compressed_bitset
-// words), finds the first one's place in the staged bucket by one binary search and walks on from there — the next
-// candidate's lower bound lies a few entries further (a window of eight slots: three halving steps at immediate offsets,
-// repeated in the rare case the window was too short).  Two chains per lane (candidates 0-3 and 4-7) keep its dependent
-// LDS reads overlapping.  The bucket is staged SKEWED (entry i at i + i / 8, the free slot repeating the next entry: still
-// ascending), so the sixteen lanes of a group — about eight entries apart — meet different LDS banks.
-// Same queries, same outputs as k_validate<false>: mask words (bit i = candidate i), the compacted survivors, the counts.
-// ---------------------------------------------------------------------------
-#define KMX_VW_E 8
-#define KMX_VW_TILE (KMX_VGROUP * KMX_VW_E)
-#define KMX_VW_STAGE ((KMX_VSTAGE + 8) * 9 / 8 + 7)      // skewed: KMX_VSTAGE entries + an 8-entry window of 0xFFFFFFFF behind them
-__global__ __launch_bounds__(KMX_BLOCK) void k_validate_walk(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_stitch,
-                                                             uint64_t* __restrict__ mask_words)
-{
-    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VW_STAGE];
-    __shared__ __attribute__((aligned(8))) uint8_t vbytes[KMX_BLOCK / KMX_WAVE][KMX_WAVE];
-    const uint32_t lane = lane_id();
-    const uint32_t wv = threadIdx.x / KMX_WAVE;
-    const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
-    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
-    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
-    auto wsync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
-    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
-        const uint64_t i = i0 + g;
-        const bool have = i < n_stitch;
-        const uint32_t q = d.stitch_list[min(i, n_stitch - 1)];
-        const uint32_t c0 = d.c0[q];
-        const uint64_t src = d.src[q] & ~SRC_FLAGS;
-        const uint64_t p1 = d.p1[q];
-        const uint64_t p1src = d.key[q];
-        const uint64_t wbase = d.aux[q];
-        uint64_t* __restrict__ words = mask_words + wbase;
-        uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + wbase * 64 : nullptr;
-        const bool fast = have && !(p1 & KMX_P1_BIG) && !stitch_is_wide(p1);    // (big: validate_big_wave; wide: k_validate_wide)
-        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
-        const bool staged = fast && pcnt <= KMX_VSTAGE;
-        const bool unstaged = fast && !staged;                                   // a bucket too long for the stage and too short for
-                                                                                  // the wide kernel's rule: searched where it lies
-        uint32_t P = (staged && pcnt > 1) ? (1u << (32 - __clz(int(pcnt - 1)))) : 1u;
-        uint32_t n_pass = fast ? (c0 + KMX_VW_TILE - 1) / KMX_VW_TILE : 0u;
-#pragma unroll
-        for (int e = 1; e < KMX_VGROUPS; ++e) {
-            P = max(P, uint32_t(__shfl_xor(int(P), e * KMX_VGROUP)));
-            n_pass = max(n_pass, uint32_t(__shfl_xor(int(n_pass), e * KMX_VGROUP)));
-        }
-        P = uint32_t(__builtin_amdgcn_readfirstlane(int(P)));
-        n_pass = uint32_t(__builtin_amdgcn_readfirstlane(int(n_pass)));
-        uint32_t* __restrict__ arr = stage[wv][g];
-        {
-            // four consecutive entries per lane and step (one 16-byte load; the arena's allocation is padded), skewed stores
-            const uint32_t nb = staged ? pcnt : 0u, last = nb ? nb - 1u : 0u;
-            const uint32_t* __restrict__ fil = arena + p1src;
-            for (uint32_t t0 = 0; t0 < P + 8; t0 += 4 * KMX_VGROUP) {
-                const uint32_t t = t0 + 4u * gl;
-                u32x4 v = *reinterpret_cast<const u32x4_a4*>(fil + min(t, last));
-                v.x = t + 0 < nb ? v.x : 0xFFFFFFFFu;
-                v.y = t + 1 < nb ? v.y : 0xFFFFFFFFu;
-                v.z = t + 2 < nb ? v.z : 0xFFFFFFFFu;
-                v.w = t + 3 < nb ? v.w : 0xFFFFFFFFu;
-                if (t < P + 8) {
-                    uint32_t* __restrict__ o = arr + (t + (t >> 3));          // (four entries never straddle a group of eight)
-                    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
-                    if ((t & 7u) == 0 && t) o[-1] = v.x;                      // the repeat in front of a group
-                }
-            }
-        }
-        wsync();
-        const KMX_LDS uint32_t* B = (const KMX_LDS uint32_t*)arr;
-        const uint32_t* __restrict__ cand = arena + src;
-        uint32_t valid = 0;
-        for (uint32_t ps = 0; ps < n_pass; ++ps) {
-            const uint32_t first = ps * KMX_VW_TILE + gl * KMX_VW_E;          // this lane's first candidate of the pass
-            const uint32_t live = (fast && first < c0) ? min(uint32_t(KMX_VW_E), c0 - first) : 0u;
-            // eight consecutive candidates through one pointer (a lane past the bucket reads on into the arena — padded — and
-            // its slots are zeroed: a 0 never moves the walk)
-            static_assert(KMX_VW_E * 4 <= KMX_ARENA_PAD, "candidates read past the last bucket stay inside the arena's padding");
-            const uint32_t* __restrict__ cp = cand + min(first, c0 ? c0 - 1u : 0u);
-            uint32_t x[KMX_VW_E];
-#pragma unroll
-            for (int j = 0; j < KMX_VW_E; ++j) x[j] = cp[j];
-#pragma unroll
-            for (int j = 0; j < KMX_VW_E; ++j) x[j] = uint32_t(j) < live ? x[j] + delta : 0u;
-            // where the first candidate of each chain belongs (log2 P halving steps over the entries)
-            constexpr int C = 2, LEN = KMX_VW_E / C;
-            uint32_t pb[C], tv[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) pb[c] = 0;
-            for (uint32_t st = P >> 1; st; st >>= 1) {
-#pragma unroll
-                for (int c = 0; c < C; ++c) { const uint32_t ii = pb[c] + st - 1; tv[c] = B[ii + (ii >> 3)]; }
-#pragma unroll
-                for (int c = 0; c < C; ++c) pb[c] += tv[c] < x[c * LEN] ? st : 0u;
-            }
-            const KMX_LDS uint32_t* pp[C];
-#pragma unroll
-            for (int c = 0; c < C; ++c) pp[c] = B + (pb[c] + (pb[c] >> 3));
-            uint32_t res = 0;
-#pragma unroll
-            for (int j = 0; j < LEN; ++j) {
-                for (;;) {
-#pragma unroll
-                    for (int st = 4; st; st >>= 1) {
-#pragma unroll
-                        for (int c = 0; c < C; ++c) tv[c] = pp[c][st - 1];
-#pragma unroll
-                        for (int c = 0; c < C; ++c) pp[c] += tv[c] < x[c * LEN + j] ? st : 0;
-                    }
-#pragma unroll
-                    for (int c = 0; c < C; ++c) tv[c] = *pp[c];
-                    bool again = false;
-#pragma unroll
-                    for (int c = 0; c < C; ++c) again |= tv[c] < x[c * LEN + j];
-                    if (!__any(again)) break;                          // (the window was too short for some chain: once more)
-                }
-#pragma unroll
-                for (int c = 0; c < C; ++c) res |= uint32_t(tv[c] == x[c * LEN + j]) << (c * LEN + j);
-            }
-            if (__any(unstaged)) {
-                if (unstaged) {
-                    res = 0;
-                    for (uint32_t j = 0; j < live; ++j) {
-                        const uint64_t lb = lower_bound_dev<uint32_t>(arena + p1src, pcnt, x[j]);
-                        res |= uint32_t(lb < pcnt && arena[p1src + lb] == x[j]) << j;
-                    }
-                }
-            }
-            res &= (1u << live) - 1u;
-            // bit i of the mask = candidate i: the lanes' verdicts are the bytes of the pass's two words
-            vbytes[wv][lane] = uint8_t(res);
-            wsync();
-            if ((gl & 7u) == 0 && fast) {
-                const uint32_t w_at = ps * 2 + gl / 8;
-                if (w_at * 64 < c0) words[w_at] = reinterpret_cast<const uint64_t*>(vbytes[wv])[lane / 8];
-            }
-            // the survivors, compacted and ascending: what k_fill copies out for this query
-            const uint32_t mine = uint32_t(__popc(res));
-            uint32_t incl = mine;
-#pragma unroll
-            for (uint32_t o = 1; o < KMX_VGROUP; o <<= 1) {
-                const uint32_t up = __shfl_up(incl, o, KMX_VGROUP);
-                if (gl >= o) incl += up;
-            }
-            const uint32_t total = uint32_t(__shfl(int(incl), KMX_VGROUP - 1, KMX_VGROUP));
-            if (sh_out && res) {
-                uint32_t at = valid + incl - mine;
-#pragma unroll
-                for (int j = 0; j < KMX_VW_E; ++j)
-                    if ((res >> j) & 1u) sh_out[at++] = x[j] - delta;
-            }
-            valid += total;
-            wsync();                                                   // vbytes are the next pass's
-        }
-        if (fast && gl == 0) {
-            if ((c0 & 63) == 0) words[c0 / 64] = 0;                     // n_bits/64 + 1 words (compressed_bitset.hpp:23)
-            d.cnt[q] = valid;
-        }
-        wsync();                                                       // stage[] is reused by the next round
-    }
-}
-
 #define KMX_VWIDE_SCAN 8
 // k_validate_wide — STITCH queries whose filter bucket has 257 ... KMX_VWIDE entries: more than a 16-lane group of k_validate
 // stages, few enough for the stage of a whole wave.  Candidates and filter bucket are both ASCENDING lists of about the same
@@ -3162,9 +2995,7 @@ void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena
         hipLaunchKernelGGL(k_validate<true>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
         return;
     }
-    static const bool old_filter = getenv("KMX_VALIDATE_SEARCH") != nullptr;      // (comparison knob: the per-candidate search)
-    if (old_filter) hipLaunchKernelGGL(k_validate<false>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
-    else hipLaunchKernelGGL(k_validate_walk, grid, block, 0, s, arena, d, n_stitch, mask_words);
+    hipLaunchKernelGGL(k_validate<false>, grid, block, 0, s, ix, arena, qranks, qoff, d, n_stitch, mask_words);
     if (n_more) {
         // (n_more counts the queries with work behind k_validate<false>: further parts, big ones, wide filter buckets)
         const uint64_t sw = (n_stitch + KMX_VWIDE_SCAN - 1) / KMX_VWIDE_SCAN;
