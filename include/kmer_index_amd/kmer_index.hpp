@@ -57,6 +57,8 @@ namespace kmer
             detail::throw_on(kmx_index_arena_host(adopted, &_arena, &n_elems), "kmer_index");
         }
 
+        bool _keep_masks = true;
+
     public:
         using result_t = detail::kmer_index_result<position_t>;
 
@@ -133,12 +135,14 @@ namespace kmer
                 for (auto const& l : q) ranks.push_back(traits::to_rank(l));
 
             kmx_result* raw = nullptr;
-            detail::throw_on(kmx_search_batch(_index.get(), ranks.data(), off.data(), queries.size(), KMX_SEARCH_KEEP_MASKS, &raw), "search");
+            detail::throw_on(kmx_search_batch(_index.get(), ranks.data(), off.data(), queries.size(),
+                                              _keep_masks ? KMX_SEARCH_KEEP_MASKS : KMX_SEARCH_DEFAULT, &raw), "search");
             std::shared_ptr<kmx_result> handle(raw, detail::result_deleter{});
             const std::uint64_t* hit_off; const std::uint32_t* positions; const std::uint8_t* status; const std::uint8_t* kinds;
             detail::throw_on(kmx_result_view(raw, &hit_off, &positions, &status, &kinds), "search");
-            const std::uint64_t* mask_base; const std::uint64_t* mask_words; const std::uint32_t* cand_count; const std::uint64_t* cand_src;
-            detail::throw_on(kmx_result_masks(raw, &mask_base, &mask_words, &cand_count, &cand_src), "search");
+            const std::uint64_t* mask_base = nullptr; const std::uint64_t* mask_words = nullptr;
+            const std::uint32_t* cand_count = nullptr; const std::uint64_t* cand_src = nullptr;
+            if (_keep_masks) detail::throw_on(kmx_result_masks(raw, &mask_base, &mask_words, &cand_count, &cand_src), "search");
 
             status_out.assign(status, status + queries.size());
             std::vector<result_t> out;
@@ -149,7 +153,7 @@ namespace kmer
                 const std::size_t n_hits = std::size_t(hit_off[i + 1] - hit_off[i]);
                 if (status[i] != KMX_Q_OK || kinds[i] == KMX_KIND_NONE)
                     out.emplace_back();
-                else if (kinds[i] == KMX_KIND_STITCH)
+                else if (kinds[i] == KMX_KIND_STITCH && _keep_masks)
                     out.emplace_back(handle, hits, n_hits, _arena + cand_src[i], std::size_t(cand_count[i]), mask_words + mask_base[i]);
                 else
                     out.emplace_back(handle, hits, n_hits);
@@ -217,6 +221,16 @@ namespace kmer
         }
 
         const kmx_index* handle() const { return _index.get(); }
+
+        // The reference's result object carries the first part's bucket and a compressed_bitset over it for cross-referenced
+        // queries (kmer_index_result.hpp:18-24): with keep == true (the default) every search asks the engine for them
+        // (KMX_SEARCH_KEEP_MASKS), which also pins the element that answers a query to the reference's planner.  A caller that
+        // only reads to_vector() / size() / iterators can turn that off: results of long queries then bypass their mask like
+        // exact ones do (should_use / should_not_use throw std::out_of_range, as on any bypass result), nothing but hit lists
+        // crosses PCIe, and the engine answers a single-k query longer than its k from the largest k that fits it — the same
+        // position lists, several times the rate on indexes with a small k (kmx.h, KMX_SEARCH_REFERENCE_PLAN).
+        void keep_masks(bool keep) { _keep_masks = keep; }
+        bool keeps_masks() const { return _keep_masks; }
 
         // the devices this index is replicated on
         std::vector<int> devices() const

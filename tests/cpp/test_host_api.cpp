@@ -126,6 +126,17 @@ void run_test(std::size_t text_size, std::uint64_t seed)
             CHECK(threw);
         }
     }
+    // without the reference's result object (keep_masks(false)): the same lists, every result bypasses its mask
+    multi_kmer.keep_masks(false);
+    auto lean = multi_kmer.search(queries);
+    CHECK(lean.size() == queries.size());
+    for (std::size_t i = 0; i < queries.size(); ++i)
+    {
+        CHECK(lean[i].to_vector() == batch[i].to_vector());
+        CHECK(lean[i].size() == 0 || lean[i].bypasses_bitmask());
+    }
+    CHECK(multi_kmer.search(queries[0]).to_vector() == batch[0].to_vector());
+    multi_kmer.keep_masks(true);
 }
 
 int main()
