@@ -372,6 +372,23 @@ def worker(args):
 
     # BASELINE configs[2..4] for the same K steps each, reported beside the headline (N = 1 only): own text, own index, the
     # same pipeline as `value`, checked by re-reading the first 2000 queries' positions and by the hit total of a second pass
+    # A query length the configs do not hold, on an index that is already built: nq_p queries of m letters (half planted),
+    # the same pipeline, checked by re-reading the first 2000 queries' positions.  Sub-k lengths and long reads: informational.
+    def length_probe(index, text_, sigma_, m_, nq_p=500_000, flags_env=None):
+        qr_p, qo_p = synth.mixed_queries(100 + m_, text_, nq_p, [m_], sigma_)
+        q_p = (torch.from_numpy(qr_p).to(dev), torch.from_numpy(qo_p.view(np.int64)).to(dev), nq_p)
+        el_p, res_p, st_p = run_sharded(index, max(3, args.steps // 4), 1, True, 1, q_p)
+        cn = res_p[0].counts()
+        ho, po, _, _ = res_p[0].host(copy=False)
+        ok = reread_ok(text_, qr_p, qo_p, ho, po, min(2000, nq_p))
+        steps_p = max(3, args.steps // 4)
+        o = {"M_queries_per_s": round(nq_p * steps_p / el_p / 1e6, 1), "G_hits_per_s": round(cn["n_hits"] * steps_p / el_p / 1e9, 1),
+             "verified": bool(ok), "queries": nq_p,
+             "kernels_avg_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st_p.items() if v["launches"]}}
+        for r_ in res_p:
+            r_.close()
+        return o
+
     def other_config(cfg):
         sg, n_c, ks_c, nq_c, ql_c, pl_c, ts_c, qs_c = CFG[cfg]
         t_c = time.time()
@@ -396,6 +413,8 @@ def worker(args):
              "workload": f"BASELINE configs[{cfg - 1}]: sigma={sg} text {n_c}, ks={ks_c}, lengths {ql_c}, planted {pl_c}", "wall_s": None}
         for r_ in res_c:
             r_.close()
+        if cfg == 3:                                                   # sub-k queries and short reads on the multi-k index
+            o["length_probes"] = {f"m={m_}": length_probe(idx_c, text_c, sg, m_, nq_p) for m_, nq_p in ((6, 50_000), (7, 200_000), (13, 500_000), (16, 500_000))}
         idx_c.close()
         del q_c
         o["wall_s"] = round(time.time() - t_c, 1)
@@ -534,6 +553,14 @@ def worker(args):
                     "what": "kmx_search_batch (queries from pageable host memory) + kmx_result_view (hit lists in host memory), end to end; "
                             "chunked: the same batch streamed through the device in 4 chunks, chunk i's copies under chunk i+1's search"}
 
+    # ---- sub-k and longer-than-k queries on the metric's own index (informational, N = 1 only) ----
+    length_probes = None
+    if world == 1 and args.config == 2 and not args.no_other_configs and rank == 0 and args.n == n_cfg:
+        length_probes = {f"m={m_}": length_probe(idx, text, args.sigma, m_) for m_ in (8, 9, 13, 25)}
+        if any(not v["verified"] for v in length_probes.values()):
+            verified = False
+            log("VERIFICATION FAILED in length_probes")
+
     other = None
     if world == 1 and args.config == 2 and not args.no_other_configs and not args.sort_queries and args.nq == nq_cfg and args.n == n_cfg:
         other = {}
@@ -543,7 +570,8 @@ def worker(args):
                 log(f"config {cfg}: {other[str(cfg)]['value']} M queries/s, verified={other[str(cfg)]['verified']}, {other[str(cfg)]['wall_s']} s")
             except Exception as e:                                    # reported, not fatal: the headline stands on its own
                 other[str(cfg)] = {"error": f"{type(e).__name__}: {e}"}
-        if any(isinstance(v, dict) and v.get("verified") is False for v in other.values()):
+        if any(isinstance(v, dict) and (v.get("verified") is False or any(not p_["verified"] for p_ in v.get("length_probes", {}).values()))
+               for v in other.values()):
             verified = False
             log("VERIFICATION FAILED in other_configs")
 
@@ -607,6 +635,7 @@ def worker(args):
             "open_addressing_table": open_leg,
             "cpu_baseline": cpu_baseline,
             "host_api": host_api,
+            "length_probes": length_probes,
             "other_configs": other,
             "kernels_avg_ms": kernels_ms,
             "verified_vs_oracle": verified,
