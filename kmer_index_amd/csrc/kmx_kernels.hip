@@ -40,7 +40,7 @@
 #define KMX_PSORT_MULTIWAY_RUNS 4   // k_prefix_sort_small: multi-way rank pass up to this many runs, bitonic beyond
 #endif
 // merge_runs_lds: steps per thread and LDS slack of the wave-level (k_prefix_merge_small) and the block-level user
-#define KMX_PM_WAVE_EMAX ((KMX_PSORT_CAP + (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2) - 1) / (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2))   // 43
+#define KMX_PM_WAVE_EMAX (((KMX_PSORT_CAP + (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2) - 1) / (KMX_WAVE - KMX_PSORT_MAX_RUNS / 2)) | 1)   // 43
 #define KMX_PM_WAVE_PAD (KMX_PSORT_MAX_RUNS + KMX_PM_WAVE_EMAX + 5)   // sentinel cells + the reads of a chunk past its end
 #define KMX_PM_TILE 4096     // k_prefix_merge_pass: output positions per workgroup (divides KMX_PSORT_BLOCK_CAP)
 #define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
@@ -2517,45 +2517,70 @@ __device__ __forceinline__ uint32_t merge_path_cut_lds(const KMX_LDS uint32_t* A
 }
 
 // E = ceil(len / (NT - ceil(R / 2))), rcp = floor(2^32 / E) + 1 (division by E as a multiplication: exact below 2^32 / E).
-template <int EMAX, int NT, typename Sync>
+// The pair table of one round (w runs per group): lanes of ONE wave, lane p = pair p -> {start, middle, end, first chunk} at
+// lpt[4 p ..], the round's chunk total at lpt[4 npairs + 3], the longest "shorter side" of any pair (bounds every merge-path
+// bracket of the round) at lpt[4 npairs + 2].
+__device__ __forceinline__ void merge_pair_table(KMX_LDS uint32_t* lpt, const KMX_LDS uint32_t* lbnd, uint32_t R, uint32_t w, uint32_t npairs,
+                                                 uint32_t E, uint32_t rcp, uint32_t lane)
+{
+    uint32_t s = 0, mi = 0, e = 0, nch = 0;
+    if (lane < npairs) {
+        const uint32_t g0 = 2 * lane;
+        s = lbnd[min(g0 * w, R)];
+        mi = lbnd[min((g0 + 1) * w, R)];
+        e = lbnd[min((g0 + 2) * w, R)];
+        nch = __umulhi(e - s + E - 1, rcp);
+    }
+    uint32_t inc = nch, longest = min(mi - s, e - mi);
+#pragma unroll
+    for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+        longest = max(longest, uint32_t(__shfl_xor(longest, o)));
+    }
+    if (lane < npairs) {
+        lpt[4 * lane] = s;
+        lpt[4 * lane + 1] = mi;
+        lpt[4 * lane + 2] = e;
+        lpt[4 * lane + 3] = inc - nch;
+    }
+    if (lane == npairs - 1) lpt[4 * npairs + 3] = inc;
+    if (lane == 0) lpt[4 * npairs + 2] = longest;
+}
+
+// E = ceil(len / (NT - ceil(R / 2))), rcp = floor(2^32 / E) + 1 (division by E as a multiplication: exact below 2^32 / E).
+// TSTRIDE > 0 (blocks of several waves; ptab holds one table of TSTRIDE words per round, ceil(log2 R) of them): the pair
+// tables of ALL rounds are written up front, wave r the table of round r, so that a round is partition - merge - barrier -
+// write back - barrier with no serial table phase in it; TSTRIDE == 0 (one wave): the table of a round is made at its start.
+template <int EMAX, int NT, int TSTRIDE, typename Sync>
 __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R, uint32_t len,
                                                uint32_t E, uint32_t rcp, uint32_t tid, Sync sync)
 {
+    constexpr bool PRETAB = TSTRIDE > 0;
+    constexpr uint32_t KMX_PM_TSTRIDE = TSTRIDE;
     KMX_LDS uint32_t* lb = (KMX_LDS uint32_t*)buf;
     const KMX_LDS uint32_t* lbnd = (const KMX_LDS uint32_t*)bnd;
-    KMX_LDS uint32_t* lpt = (KMX_LDS uint32_t*)ptab;
+    KMX_LDS uint32_t* lpt0 = (KMX_LDS uint32_t*)ptab;
     const uint32_t lane = tid & (KMX_WAVE - 1);
-    uint32_t w = 1, ngroups = R;
+    if (PRETAB) {
+        uint32_t r = tid / KMX_WAVE, w = 1u << r;
+        for (; w < R; r += NT / KMX_WAVE, w <<= NT / KMX_WAVE) {
+            const uint32_t ngroups = (R + w - 1) / w;
+            merge_pair_table(lpt0 + r * KMX_PM_TSTRIDE, lbnd, R, w, (ngroups + 1) >> 1, E, rcp, lane);
+        }
+        sync();
+    }
+    uint32_t w = 1, ngroups = R, rnd = 0;
     bool first = true;
     while (ngroups > 1) {
         const uint32_t npairs = (ngroups + 1) >> 1;
-        if (tid < KMX_WAVE) {                                     // the pair table: {start, middle, end, first chunk}
-            uint32_t s = 0, mi = 0, e = 0, nch = 0;
-            if (tid < npairs) {
-                const uint32_t g0 = 2 * tid;
-                s = lbnd[min(g0 * w, R)];
-                mi = lbnd[min((g0 + 1) * w, R)];
-                e = lbnd[min((g0 + 2) * w, R)];
-                nch = __umulhi(e - s + E - 1, rcp);
-                if (!first && e == mi) lb[mi + 2 * tid + 1] = KMX_PM_SENT;      // the empty partner of an unpaired group
-            }
-            uint32_t inc = nch, longest = min(mi - s, e - mi);
-#pragma unroll
-            for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
-                const uint32_t t = __shfl_up(inc, o);
-                if (lane >= o) inc += t;
-                longest = max(longest, uint32_t(__shfl_xor(longest, o)));
-            }
-            if (tid < npairs) {
-                lpt[4 * tid] = s;
-                lpt[4 * tid + 1] = mi;
-                lpt[4 * tid + 2] = e;
-                lpt[4 * tid + 3] = inc - nch;
-            }
-            if (tid == npairs - 1) lpt[4 * npairs + 3] = inc;     // chunks in all
-            if (tid == 0) lpt[4 * npairs + 2] = longest;          // the longest "shorter side" of any pair: bounds every bracket
+        KMX_LDS uint32_t* lpt = PRETAB ? lpt0 + rnd * KMX_PM_TSTRIDE : lpt0;
+        if (!PRETAB) {
+            if (tid < KMX_WAVE) merge_pair_table(lpt, lbnd, R, w, npairs, E, rcp, lane);
+            sync();
+            if (!first && tid < npairs && lpt[4 * tid + 2] == lpt[4 * tid + 1]) lb[lpt[4 * tid + 1] + 2 * tid + 1] = KMX_PM_SENT;   // the empty
+            if (!first) sync();                                                                     // partner of an unpaired group
         }
-        sync();
         const uint32_t total = lpt[4 * npairs + 3];
         uint32_t steps = 0;
         {
@@ -2594,10 +2619,17 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
         if (first) round(std::true_type{});
         else round(std::false_type{});
         if (tid < npairs) lb[lpt[4 * tid + 2] + tid] = KMX_PM_SENT;   // the cell behind every merged group
+        if (PRETAB && npairs > 1) {
+            // the next round's unpaired group (if any) merges with an empty partner: its sentinel, in the layout just written
+            const KMX_LDS uint32_t* nxt = lpt0 + (rnd + 1) * KMX_PM_TSTRIDE;
+            const uint32_t np2 = (npairs + 1) >> 1;
+            if (tid < np2 && nxt[4 * tid + 2] == nxt[4 * tid + 1]) lb[nxt[4 * tid + 1] + 2 * tid + 1] = KMX_PM_SENT;
+        }
         sync();
         w <<= 1;
         ngroups = npairs;
         first = false;
+        ++rnd;
     }
 }
 
@@ -2845,10 +2877,11 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_small(const KmxIndex
         const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);
         if (lane <= R) bnd[wv][lane] = offs[lane] - offs[0];
         for (uint32_t t = lane; t < len; t += KMX_WAVE) buf[wv][1 + t] = srcp[t];
-        const uint32_t E = max(2u, (len + (KMX_WAVE - (R + 1) / 2) - 1) / (KMX_WAVE - (R + 1) / 2));
+        // (an ODD chunk length: the lanes' places in the buffer are E words apart — an even E maps them onto a fraction of the LDS banks)
+        const uint32_t E = max(3u, ((len + (KMX_WAVE - (R + 1) / 2) - 1) / (KMX_WAVE - (R + 1) / 2)) | 1u);
         const uint32_t rcp = 0xFFFFFFFFu / E + 1;
         wsync();
-        merge_runs_lds<KMX_PM_WAVE_EMAX, KMX_WAVE>(buf[wv] + 1, bnd[wv], ptab[wv], R, len, E, rcp, lane, wsync);
+        merge_runs_lds<KMX_PM_WAVE_EMAX, KMX_WAVE, 0>(buf[wv] + 1, bnd[wv], ptab[wv], R, len, E, rcp, lane, wsync);
         uint32_t* __restrict__ seg = out + hit_off[q];
         for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][1 + t];
         wsync();                                                               // buf / bnd / ptab are the next query's
@@ -3122,8 +3155,10 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 // 256 threads around 33 KB (four per CU: one block's staging and copy-out overlap the others' rounds).
 template <int THREADS, int CAP, int RUNS>
 struct PsbShape {
-    static constexpr int EMAX = (CAP + (THREADS - RUNS / 2) - 1) / (THREADS - RUNS / 2);
+    static constexpr int EMAX = ((CAP + (THREADS - RUNS / 2) - 1) / (THREADS - RUNS / 2)) | 1;
     static constexpr int WORDS = CAP + RUNS + EMAX + 5;      // staged chunk + sentinel cells + the reads of a chunk past its end
+    static constexpr int TSTRIDE = 4 * (RUNS / 2 + 1);       // words of one round's pair table
+    static constexpr int ROUNDS = RUNS <= 64 ? 6 : 7;        // ceil(log2 RUNS)
 };
 typedef PsbShape<1024, KMX_PSORT_BLOCK_CAP, 128> PsbBig;
 typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
@@ -3141,7 +3176,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
     extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
     __shared__ uint32_t bnd[RUNS + 1];
-    __shared__ uint32_t ptab[4 * (RUNS / 2 + 1)];
+    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
     __shared__ uint32_t runs[2];
     const uint32_t tid = threadIdx.x;
     for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
@@ -3178,8 +3213,8 @@ __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev
             for (uint32_t t = tid; t < n_stage; t += THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
             __syncthreads();
             if (merge) {
-                const uint32_t E = max(2u, (c_len + (THREADS - (Rc + 1) / 2) - 1) / (THREADS - (Rc + 1) / 2));
-                merge_runs_lds<Shape::EMAX, THREADS>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+                const uint32_t E = max(3u, ((c_len + (THREADS - (Rc + 1) / 2) - 1) / (THREADS - (Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
+                merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
             } else {
                 bitonic_lds(sbuf, n2, tid, uint32_t(THREADS), [] { __syncthreads(); });
             }
