@@ -626,7 +626,7 @@ def worker(args):
                                    f"(lengths {qlens}, planted share {planted}), materialised sorted position lists (to_vector), table={args.table}"
                                    f"{'(dense)' if info['tables'][0] == engine.TABLE_DENSE else '(open)'}",
                        "queries_per_gpu": nq, "hits_per_step_per_gpu": n_hits_rank, "total_hits_all_gpus": total_hits,
-                       "index_device_bytes": info["device_bytes"], "parallelism": f"query-shard x{world}, index replicated",
+                       "index_device_bytes": info["device_bytes"], "index_memory": idx.memory(), "parallelism": f"query-shard x{world}, index replicated",
                        "gather": "totals", "pipeline_depth": depth, "streams": max(1, min(args.streams, depth))},
             "roofline": roofline,
             "rccl": rccl,

@@ -165,6 +165,14 @@ kmx_status kmx_index_info(const kmx_index* index, uint64_t* n, uint32_t* sigma, 
                           uint32_t* ks /* KMX_MAX_KS */, uint32_t* table_kinds /* KMX_MAX_KS */,
                           uint64_t* device_bytes);
 
+/* What the device memory of one replica (kmx_index_info's device_bytes) is made of, in bytes: the position arrays proper
+ * (4 bytes per k-mer start and element — the reference's buckets), and the layouts DERIVED from them that an options field or
+ * an environment variable turns off: the 128-byte-line-aligned copy of long buckets and the cells of short ones
+ * (no_aligned_copy), the prefix levels (prefix_levels); `tables` is the rest (offset / slot / key tables, directories, padding,
+ * planner tables, tail).  Any pointer may be NULL. */
+kmx_status kmx_index_memory(const kmx_index* index, uint64_t* positions, uint64_t* aligned_copy, uint64_t* cells,
+                            uint64_t* prefix_levels, uint64_t* tables);
+
 /* kmer_index::extend_query_size_range(new_maximum) (kmer_index.hpp:498-502): rebuilds the planner
  * table for query lengths < new_maximum and installs it.  Must not run concurrently with a search
  * on the same index. */

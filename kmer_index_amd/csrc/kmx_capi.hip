@@ -179,6 +179,7 @@ struct kmx_index {
     std::vector<uint32_t> table_kinds;
     std::vector<void*> allocs;          // device allocations owned by the index
     uint64_t device_bytes = 0;
+    uint64_t bytes_positions = 0, bytes_aligned = 0, bytes_cells = 0, bytes_levels = 0;   // parts of device_bytes (kmx_index_memory)
     KmxIndexDev* d_index = nullptr;     // device copy of the header
     KmxIndexDev* d_index_fast = nullptr; // the same header around the engine's own planner table (kmx::make_fast_plan_entries): every search but KEEP_MASKS ones
     const KmxPlanEntry* d_plan_fast = nullptr;
@@ -466,6 +467,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         el.n_ukeys = uint32_t(im.d_ukeys_prebuilt ? im.n_ukeys_prebuilt : im.ukeys.size());
         if (im.region > im.npos) base = (base + 31) & ~uint64_t(31);
         el.n_keys = im.n_keys; el.arena_base = base; el.npos = im.npos; el.region = im.region; el.atab = nullptr;
+        ix->bytes_positions += im.npos * 4; ix->bytes_aligned += (im.region - im.npos) * 4;
         ix->table_kinds.push_back(im.table_kind);
         ix->elem_sizes.push_back({im.offs.size(), im.slots.size(), im.ukeys.size(),
                                   (im.d_atab_prebuilt || (im.table_kind == KMX_TABLE_DENSE && !im.atab.empty())) ? size_t(im.n_keys + 1) : size_t(0)});
@@ -537,6 +539,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
             }
             if (ce != hipSuccess) { fail(ce == hipErrorOutOfMemory ? KMX_ERR_OUT_OF_MEMORY : KMX_ERR_HIP, std::string("cells: ") + hipGetErrorString(ce)); return bail(KMX_ERR_HIP); }
             el.cnt8 = static_cast<const uint8_t*>(p);
+            ix->bytes_cells += ((im.n_keys << cell_shift[i]) * 4) + im.n_keys;
             el.cell_base = cell_base[i];
             el.cell_shift = cell_shift[i];
             if (o.keep_host_arena) {                                       // candidate runs of STITCH queries may lie in cells
@@ -579,6 +582,7 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
     ix->n = src->n; ix->sigma = src->sigma; ix->range = src->range;
     ix->ks = src->ks; ix->table_kinds = src->table_kinds; ix->elem_sizes = src->elem_sizes; ix->tail = src->tail;
     ix->fill_variant = src->fill_variant; ix->rec32 = src->rec32;
+    ix->bytes_positions = src->bytes_positions; ix->bytes_aligned = src->bytes_aligned; ix->bytes_cells = src->bytes_cells; ix->bytes_levels = src->bytes_levels;
     auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
     hipError_t e = hipSetDevice(device);
     if (e != hipSuccess) { fail(KMX_ERR_NO_DEVICE, std::string("replica device: ") + hipGetErrorString(e)); return bail(KMX_ERR_NO_DEVICE); }
@@ -733,6 +737,7 @@ static kmx_status add_prefix_levels_impl(kmx_index* ix, const kmx_options& o)
             ix->allocs.erase(std::remove(ix->allocs.begin(), ix->allocs.end(), old), ix->allocs.end());
             ix->allocs.push_back(grown);
             ix->device_bytes += (new_elems - h.arena_elems) * 4;
+            ix->bytes_levels += (new_elems - h.arena_elems) * 4;
             h.arena = g; ix->d_arena = g;
             h.arena_elems = new_elems;
             el.lvl_offs_at[L - 1] = offs_at;
@@ -1164,6 +1169,19 @@ kmx_status kmx_index_info(const kmx_index* ix, uint64_t* n, uint32_t* sigma, uin
         if (table_kinds) table_kinds[i] = ix->table_kinds[i];
     }
     if (device_bytes) *device_bytes = ix->device_bytes;          // per replica
+    return KMX_OK;
+}
+
+kmx_status kmx_index_memory(const kmx_index* ix, uint64_t* positions, uint64_t* aligned_copy, uint64_t* cells, uint64_t* prefix_levels,
+                            uint64_t* tables)
+{
+    if (!ix) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_memory: index is NULL");
+    if (positions) *positions = ix->bytes_positions;
+    if (aligned_copy) *aligned_copy = ix->bytes_aligned;
+    if (cells) *cells = ix->bytes_cells;
+    if (prefix_levels) *prefix_levels = ix->bytes_levels;
+    const uint64_t parts = ix->bytes_positions + ix->bytes_aligned + ix->bytes_cells + ix->bytes_levels;
+    if (tables) *tables = ix->device_bytes > parts ? ix->device_bytes - parts : 0;
     return KMX_OK;
 }
 

@@ -20,7 +20,7 @@ Q_OK, Q_TOO_LONG, Q_SUBK_FANOUT, Q_EMPTY_QUERY, Q_BAD_RANK = 0, 1, 2, 3, 4
 
 # every symbol include/kmx.h declares
 EXPORTS = [
-    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_choose_best_k", "kmx_plan", "kmx_plan_engine", "kmx_fast_pow",
+    "kmx_index_build", "kmx_index_free", "kmx_index_save", "kmx_index_load", "kmx_index_info", "kmx_index_memory", "kmx_index_arena_host", "kmx_index_extend_query_size_range", "kmx_choose_best_k", "kmx_plan", "kmx_plan_engine", "kmx_fast_pow",
     "kmx_search_batch", "kmx_search_batch_device", "kmx_result_counts", "kmx_result_view_device",
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
@@ -73,6 +73,8 @@ def lib():
         L.kmx_index_load.argtypes = [C.c_char_p, P(Options), P(vp)]
         L.kmx_index_info.restype = C.c_int
         L.kmx_index_info.argtypes = [vp, P(u64), P(u32), P(u32), vp, vp, P(u64)]
+        L.kmx_index_memory.restype = C.c_int
+        L.kmx_index_memory.argtypes = [vp, P(u64), P(u64), P(u64), P(u64), P(u64)]
         L.kmx_index_arena_host.restype = C.c_int
         L.kmx_index_arena_host.argtypes = [vp, P(vp), P(u64)]
         L.kmx_index_extend_query_size_range.restype = C.c_int
@@ -310,6 +312,12 @@ class Index:
         _check(lib().kmx_index_info(self._h, C.byref(n), C.byref(sigma), C.byref(nks), ks.ctypes.data, tk.ctypes.data, C.byref(dbytes)))
         return {"n": n.value, "sigma": sigma.value, "ks": ks[:nks.value].tolist(), "tables": tk[:nks.value].tolist(),
                 "device_bytes": dbytes.value}
+
+    def memory(self):
+        """kmx_index_memory: device bytes of one replica by part (positions, aligned_copy, cells, prefix_levels, tables)."""
+        v = [C.c_uint64() for _ in range(5)]
+        _check(lib().kmx_index_memory(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(["positions", "aligned_copy", "cells", "prefix_levels", "tables"], [int(x.value) for x in v]))
 
     def devices(self):
         n = C.c_uint32()

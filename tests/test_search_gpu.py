@@ -685,6 +685,9 @@ def test_prefix_levels_answer_like_the_merge(engine, orc, sigma, ks, levels):
     without = engine.Index(text, sigma, ks, prefix_levels=-1)
     oidx = orc.Index(text, sigma, ks)
     assert with_lv.info()["device_bytes"] >= without.info()["device_bytes"] + 4 * (text.size - max(ks))
+    mw, mo = with_lv.memory(), without.memory()
+    assert mo["prefix_levels"] == 0 and mw["prefix_levels"] >= 4 * (text.size - max(ks)) and mw["positions"] == mo["positions"] == 4 * sum(text.size - k + 1 for k in ks)
+    assert sum(mw.values()) == with_lv.info()["device_bytes"] and sum(mo.values()) == without.info()["device_bytes"]
     qs = []
     rng = np.random.default_rng(7)
     for m in range(1, max(ks)):
