@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from kmer_index_amd import synth
-from tests.helpers import make_queries
+from tests.helpers import make_queries, pack
 
 pytestmark = pytest.mark.gpu
 
@@ -225,6 +225,29 @@ def test_batches_too_large_for_one_pass_are_streamed_in_chunks(engine, monkeypat
     r5 = idx.search(q, off, flags=engine.SEARCH_KEEP_MASKS, result=r1)
     assert _same(r5.host(), want) and r5.counts() == c1
     rc.close(); r5.close(); idx.close()
+
+
+def test_chunked_batches_whose_hits_arrive_late_and_count_only(engine, monkeypatch):
+    """The chunk-streamed form sizes its host view of the positions from the first chunk's hits per query and grows it when a
+    later chunk proves that short: a batch whose first chunks find next to nothing and whose last ones find tens of thousands
+    of positions per query; the same batch count-only (no positions cross PCIe)."""
+    text = synth.ranks(2025, 300_000, 4)
+    idx = engine.Index(text, 4, [8, 11])
+    rng = np.random.default_rng(8)
+    qs = [rng.integers(0, 4, 30).astype(np.uint8) for _ in range(2500)]                       # random 30-mers: no hits
+    qs += [text[s0:s0 + 8].copy() for s0 in range(100, 1100)]                                 # exact 8-mers: a few hits each
+    qs += [text[s0:s0 + m].copy() for m in (3, 2, 4) for s0 in range(5000, 5300)]             # sub-k: thousands of hits each
+    q, off = pack(qs)
+    want = idx.search(q, off).host()
+    monkeypatch.setenv("KMX_HOST_CHUNK", "500")
+    rc = idx.search(q, off)
+    assert rc.n_parts() == (len(qs) + 499) // 500 and _same(rc.host(), want)
+    rc2 = idx.search(q, off, result=rc)                                                       # the grown views are reused
+    assert _same(rc2.host(), want)
+    rco = idx.search(q, off, flags=engine.SEARCH_COUNT_ONLY)
+    h = rco.host()
+    assert np.array_equal(h[0], want[0]) and h[1].size == 0 and np.array_equal(h[2], want[2])
+    rc.close(); rco.close(); idx.close()
 
 
 def test_no_device_memory_is_leaked(engine, monkeypatch):

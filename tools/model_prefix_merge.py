@@ -14,11 +14,13 @@ def merge_runs(vals, bnd, NT, EMAX, slack=64):
     n = bnd[R]
     buf = list(vals) + [0xDEADBEEF] * (R + EMAX + slack)       # garbage beyond: reads there must be harmless
     w, ngroups, first = 1, R, True
+    # ONE chunk length for every round, from the first round's pair count (later rounds have fewer pairs, so the chunks of a
+    # round never outnumber the threads); odd, so that the lanes' places in the buffer spread over the LDS banks
+    E = max(3, (-(-n // (NT - (R + 1) // 2))) | 1)
+    assert E <= EMAX, (E, EMAX, n, NT, R)
     while ngroups > 1:
         npairs = (ngroups + 1) // 2
         assert npairs < NT
-        E = max(1, -(-n // (NT - npairs)))
-        assert E <= EMAX, (E, EMAX, n, NT, npairs)
         # pair table (threads 0..npairs-1)
         ptab, c0 = [], 0
         for p in range(npairs):
@@ -90,9 +92,9 @@ def merge_runs(vals, bnd, NT, EMAX, slack=64):
     return buf[:n]
 
 
-def main():
+def main(cases=3000):
     rnd = random.Random(5)
-    for case in range(3000):
+    for case in range(cases):
         NT = rnd.choice([64, 64, 256, 1024])
         R = rnd.randint(1, min(32 if NT == 64 else 64, NT // 2))
         n = rnd.randint(0, rnd.choice([40, 300, 2048]))
@@ -103,7 +105,7 @@ def main():
         vals = []
         for r in range(R):
             vals += sorted(pool[bnd[r]:bnd[r + 1]])
-        EMAX = max(1, -(-max(n, 1) // (NT - (R + 1) // 2)))
+        EMAX = max(3, (-(-max(n, 1) // (NT - (R + 1) // 2))) | 1)
         got = merge_runs(vals, bnd, NT, EMAX)
         assert got == sorted(vals), (case, NT, R, n)
     print("model ok")
