@@ -483,6 +483,21 @@ def worker(args):
         if world == 1 and not args.no_cpu_baseline and args.config == 2:
             t1 = time.time()
             usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            # a CPU-time quota of the container (cgroup) caps what any number of threads can get: the all-cores leg then says
+            # what the quota is worth, not what the host's cores are
+            quota_cores = None
+            try:
+                txt = open("/sys/fs/cgroup/cpu.max").read().split()
+                if txt and txt[0] != "max":
+                    quota_cores = float(txt[0]) / float(txt[1])
+            except Exception:
+                try:
+                    q_us = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+                    p_us = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    if q_us > 0:
+                        quota_cores = q_us / p_us
+                except Exception:
+                    pass
             T = args.cpu_threads or max(1, min(16, usable))
             oidx = orc.Index(text, args.sigma, ks, n_threads=T)
             log(f"oracle (CPU restatement) index built in {time.time() - t1:.1f}s")
@@ -514,7 +529,9 @@ def worker(args):
                                       + f" ({T} threads of {usable} usable, {cpu_model}; std::unordered_map buckets in place of robin_hood), {dt:.1f}s wall",
                             "single_thread_value": round(n1 / dt1 / 1e6, 4), "single_thread_sample": f"first {n1} queries, {dt1:.1f}s",
                             "all_cores_value": round(ns / dt_all / 1e6, 4) if dt_all else None, "all_cores": usable if dt_all else None,
-                            "all_cores_sample": f"the same {ns} queries on all {usable} usable hardware threads, {dt_all:.1f}s wall" if dt_all else None}
+                            "all_cores_sample": (f"the same {ns} queries on all {usable} usable hardware threads, {dt_all:.1f}s wall"
+                                                 + (f"; the container's CPU quota is {quota_cores:.1f} cores, which is what this leg measures" if quota_cores else "; no CPU quota found (cgroup)")) if dt_all else None,
+                            "cpu_quota_cores": quota_cores}
             o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
             oidx.close()
