@@ -508,7 +508,7 @@ def worker(args):
             dt = time.perf_counter() - t1
             # "T = hardware_concurrency, also T = 1" — the same sample on every usable core (chunked >= 4 T by the batch)
             dt_all = None
-            if usable > T:
+            if usable > T and not (quota_cores and quota_cores <= T + 0.5):      # (a quota of T cores: more threads only share them)
                 t1 = time.perf_counter()
                 oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=usable, keep_hits=False, reference_pool=ref_pool)
                 dt_all = time.perf_counter() - t1
@@ -531,7 +531,10 @@ def worker(args):
                             "all_cores_value": round(ns / dt_all / 1e6, 4) if dt_all else None, "all_cores": usable if dt_all else None,
                             "all_cores_sample": (f"the same {ns} queries on all {usable} usable hardware threads, {dt_all:.1f}s wall"
                                                  + (f"; the container's CPU quota is {quota_cores:.1f} cores, which is what this leg measures" if quota_cores else "; no CPU quota found (cgroup)")) if dt_all else None,
-                            "cpu_quota_cores": quota_cores}
+                            "cpu_quota_cores": quota_cores,
+                            "all_cores_skipped": (f"the container's CPU quota is {quota_cores:.1f} cores: {usable} threads would only share them "
+                                                  f"(measured once: 11.2-11.7 M queries/s on 256 threads against 11.6-14.6 on 16, BASELINE.md)")
+                                                 if (dt_all is None and quota_cores and usable > T) else None}
             o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
             oidx.close()
