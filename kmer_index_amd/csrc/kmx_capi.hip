@@ -13,6 +13,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -1801,8 +1802,7 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
             if (h0)
                 for (uint64_t q = q0 + 1; q <= q1; ++q) parent->v_hit_off[q] += h0;
             if (masks) {
-                tasks[turn].running = true;
-                tasks[turn].th = std::thread([&, turn, w, part, q0, cq] {
+                auto masks_only = [&, turn, w, part, q0, cq] {
                     // (masks only: reuse the copy task with nothing else left to move)
                     CopyTask& t = tasks[turn];
                     const uint64_t* mb = nullptr; const uint64_t* mw = nullptr; const uint32_t* cc = nullptr; const uint64_t* cs2 = nullptr;
@@ -1817,11 +1817,21 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
                     part->m_base = part->h_mask_base.as<uint64_t>(); part->m_words = part->h_mask_words.as<uint64_t>();
                     part->m_ccnt = part->h_cand_count.as<uint32_t>(); part->m_csrc = part->h_cand_src.as<uint64_t>();
                     (void)q0;
-                });
+                };
+                try {
+                    tasks[turn].th = std::thread(masks_only);
+                    tasks[turn].running = true;
+                } catch (const std::system_error&) {
+                    masks_only();
+                }
             }
         } else {
-            tasks[turn].running = true;
-            tasks[turn].th = std::thread(copy_out, turn, w, part, q0, cq, h0);
+            try {
+                tasks[turn].th = std::thread(copy_out, turn, w, part, q0, cq, h0);
+                tasks[turn].running = true;
+            } catch (const std::system_error&) {                // no thread to be had: the copies run here, in line
+                copy_out(turn, w, part, q0, cq, h0);
+            }
         }
         h0 += w->n_hits;
         q0 = q1;
