@@ -29,8 +29,10 @@
 //   ORC_MODE_FAITHFUL : restates the reference's control flow line by line,
 //                       including its >=3-part defects (kmer_index.hpp:314,
 //                       :526, :535) with the two undefined dereferences
-//                       (:317, :546) given the defined meaning "mismatch".
-//   ORC_MODE_INTENDED : the same algorithm with those three lines repaired
+//                       (:317, :546) given the defined meaning "mismatch",
+//                       and the 32-bit `int last_hash` of :214-226 (a false
+//                       "same hash as the previous part" once sigma^k > 2^32).
+//   ORC_MODE_INTENDED : the same algorithm with those lines repaired
 //                       (what to_vector() is documented to mean: every text
 //                       offset where the query occurs, ascending).
 // Inside the SURVEY §4.3 envelope both modes and the naive scan agree.
@@ -237,16 +239,24 @@ struct element {
         if (m > k) {                                                                           // :207-339
             uint64_t rest_n = m % k;
             std::vector<const bucket_t*> nk;
+            // :214 `int last_hash = -1;` — :219 compares the size_t hash with that int (the int is converted to size_t,
+            // i.e. SIGN-EXTENDED), :226 stores the hash back into it (truncated to 32 bits).  Consequences, restated exactly in
+            // FAITHFUL mode: a previous hash in [2^31, 2^32) never compares equal (shortcut off, harmless); a previous hash
+            // >= 2^32 whose bit 31 is clear compares equal to the hash `prev & 0xFFFFFFFF` — a DIFFERENT k-mer — and the
+            // reference then reuses the PREVIOUS part's bucket for it (defect 4; reachable once sigma^k > 2^32, e.g. DNA4 k >= 17).
+            // INTENDED mode keeps the full hash: the shortcut only ever skips a lookup that would return the same bucket.
+            int32_t last_hash = -1;
             bool have_last = false;
-            uint64_t last_hash = 0;
+            uint64_t last_full = 0;
             for (uint64_t i = 0; i < m - rest_n; i += k) {                                     // :216-227
                 uint64_t h = hash(q + i);
-                // :214/:219 keep the previous hash in an `int`; the truncation only
-                // disables this shortcut for k >= 16 and never changes the bucket.
-                const auto* pos = (have_last && h == last_hash) ? nk.back() : at(h);
+                const bool same = (mode == MODE_FAITHFUL) ? (h == uint64_t(int64_t(last_hash)) && !nk.empty())
+                                                          : (have_last && h == last_full);
+                const auto* pos = same ? nk.back() : at(h);                                    // :219
                 if (!pos) return result();
                 nk.push_back(pos);
-                last_hash = h; have_last = true;
+                last_hash = int32_t(uint32_t(h));                                              // :226
+                last_full = h; have_last = true;
             }
             bitset usable(nk.back()->size(), true);                                            // :230
             if (rest_n > 0) {                                                                  // :232-256

@@ -187,3 +187,50 @@ def test_batch_on_thread_pool_matches_serial(orc):
     a = idx.search_batch(q, off, n_threads=1)
     b = idx.search_batch(q, off, n_threads=7)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+def test_last_hash_int_truncation_is_restated(orc):
+    """Defect 4 (kmer_index.hpp:214-226): `int last_hash` keeps 32 bits of the previous part's hash and is sign-extended in
+    the comparison at :219.  With sigma^k > 2^32 (DNA4, k >= 17) a part whose hash is h >= 2^32 with bit 31 clear, followed
+    by the part whose hash is h & 0xFFFFFFFF, makes the reference reuse the FIRST part's bucket for the second.
+    FAITHFUL restates that; INTENDED == naive scan is what the engine answers (tests/test_search_gpu.py)."""
+    sigma, k = 4, 17
+    # part1: first letter != 0 (hash >= 2^32), second letter in {0, 1} (bit 31 clear); part2 = 'A' + part1[1:]  (hash = low 32 bits)
+    part1 = np.array([2, 1] + [3, 0, 2, 1, 1, 3, 2, 0, 3, 1, 2, 2, 0, 1, 3], np.uint8)
+    part2 = part1.copy()
+    part2[0] = 0
+    h1 = sum(int(r) << (2 * (k - 1 - i)) for i, r in enumerate(part1))
+    h2 = sum(int(r) << (2 * (k - 1 - i)) for i, r in enumerate(part2))
+    assert h1 >= 1 << 32 and not (h1 >> 31) & 1 and h2 == h1 & 0xFFFFFFFF
+    text = synth.ranks(4242, 6000, sigma)
+    text[1000:1000 + k] = part1; text[1000 + k:1000 + 2 * k] = part2          # a true occurrence of part1 + part2
+    text[3000:3000 + k] = part1; text[3000 + k:3000 + 2 * k] = part1          # part1 twice in a row: NOT an occurrence
+    idx = orc.Index(text, sigma, [k])
+    q = np.concatenate([part1, part2])
+    truth = orc.naive_scan(text, q)
+    assert truth.tolist() == [1000]
+    st_i, got_i = idx.search(q, mode=orc.MODE_INTENDED)
+    st_f, got_f = idx.search(q, mode=orc.MODE_FAITHFUL)
+    assert st_i == orc.ST_OK and st_f == orc.ST_OK
+    assert got_i.tolist() == [1000]                                             # INTENDED == naive
+    assert got_f.tolist() == [3000]                                             # the reference: first part's bucket used twice
+    # the false equality needs the truncation: the same construction one letter shorter (4^16 = 2^32: every hash < 2^32
+    # equals its own low word, and hashes in [2^31, 2^32) compare unequal after sign extension) is answered correctly
+    k2 = 16
+    p1, p2 = part1[:k2].copy(), part2[:k2].copy()
+    t2 = synth.ranks(4243, 6000, sigma)
+    t2[1000:1000 + k2] = p1; t2[1000 + k2:1000 + 2 * k2] = p2
+    t2[3000:3000 + k2] = p1; t2[3000 + k2:3000 + 2 * k2] = p1
+    idx2 = orc.Index(t2, sigma, [k2])
+    q2 = np.concatenate([p1, p2])
+    for mode in (orc.MODE_INTENDED, orc.MODE_FAITHFUL):
+        assert idx2.search(q2, mode=mode)[1].tolist() == orc.naive_scan(t2, q2).tolist() == [1000]
+    # a previous hash in [2^31, 2^32): never "equal" after sign extension, even when the next part IS the same k-mer
+    p3 = np.array([2] + [1] * 15, np.uint8)                                     # hash = 2 << 30 | ... >= 2^31
+    t3 = synth.ranks(4244, 6000, sigma)
+    t3[500:500 + k2] = p3; t3[500 + k2:500 + 2 * k2] = p3
+    idx3 = orc.Index(t3, sigma, [k2])
+    q3 = np.concatenate([p3, p3])
+    for mode in (orc.MODE_INTENDED, orc.MODE_FAITHFUL):
+        assert idx3.search(q3, mode=mode)[1].tolist() == orc.naive_scan(t3, q3).tolist()
+    idx.close(); idx2.close(); idx3.close()

@@ -95,6 +95,30 @@ def test_outside_the_envelope_the_engine_follows_ground_truth_not_the_reference(
         idx.close()
 
 
+def test_the_engine_does_not_reproduce_the_int_last_hash_defect(engine, orc):
+    """Defect 4 (kmer_index.hpp:214-226, `int last_hash`): with sigma^k > 2^32 the reference reuses the previous part's bucket
+    for a part whose hash equals the previous hash's low 32 bits.  The engine answers ground truth (== naive == INTENDED), which
+    here is NOT the faithful restatement's answer; CPU twin: tests/test_oracle_cpu.py::test_last_hash_int_truncation_is_restated."""
+    sigma, k = 4, 17
+    part1 = np.array([2, 1] + [3, 0, 2, 1, 1, 3, 2, 0, 3, 1, 2, 2, 0, 1, 3], np.uint8)
+    part2 = part1.copy()
+    part2[0] = 0
+    text = synth.ranks(4242, 6000, sigma)
+    text[1000:1000 + k] = part1; text[1000 + k:1000 + 2 * k] = part2
+    text[3000:3000 + k] = part1; text[3000 + k:3000 + 2 * k] = part1
+    qs = [np.concatenate([part1, part2]), np.concatenate([part1, part1]), np.concatenate([part2, part1])]
+    qranks, qoff = pack(qs)
+    for keep in (False, True):
+        idx = engine.Index(text, sigma, [k])
+        hit_off, positions, status, kinds = idx.search(qranks, qoff, flags=engine.SEARCH_DEFAULT | (engine.SEARCH_KEEP_MASKS if keep else 0)).host()
+        oidx = orc.Index(text, sigma, [k])
+        lists = [positions[int(hit_off[i]):int(hit_off[i + 1])].tolist() for i in range(3)]
+        assert lists == [orc.naive_scan(text, q).tolist() for q in qs] == [[1000], [3000], []]
+        assert [oidx.search(q, mode=orc.MODE_INTENDED)[1].tolist() for q in qs] == lists
+        assert oidx.search(qs[0], mode=orc.MODE_FAITHFUL)[1].tolist() == [3000]      # what the reference would return
+        idx.close()
+
+
 @pytest.mark.parametrize("sigma,ks", [(4, [8, 10, 12]), (20, [3, 5]), (4, [6, 9])])
 def test_engine_plan_and_reference_plan_return_the_same_lists(engine, orc, sigma, ks):
     """A single-k query longer than its k is answered from the largest k that fits (kmx_plan_engine) unless the call asks for
