@@ -72,6 +72,7 @@ def parse_args(argv=None):
                     help="N=1, config 2 only: skip the legs that run BASELINE configs[2..4] (--config 3/4/5) for the same K steps and "
                          "report them as other_configs in the same JSON line")
     ap.add_argument("--cpu-sample", type=int, default=10_000_000, help="queries in the CPU baseline sample")
+    ap.add_argument("--cpu-passes", type=int, default=5, help="timed passes of every CPU baseline leg (>= 5; one warm-up pass in front)")
     ap.add_argument("--cpu-threads", type=int, default=0, help="CPU baseline threads (0 = min(16, usable cores): the box's CPU share)")
     ap.add_argument("--verify", type=int, default=20000, help="queries checked against the oracle after timing")
     ap.add_argument("--sort-queries", action="store_true",
@@ -370,6 +371,46 @@ def worker(args):
             ok &= bool((pos[1:][same_q] > pos[:-1][same_q]).all())
         return bool(ok)
 
+    def windows_complete_ok(text_, sigma_, qr_, qo_, hit_off_, positions_, nv_, W=4_000_000):
+        # COMPLETENESS of the first nv_ queries' lists inside two windows of the text (its first and its last W letters: the tail
+        # is where the last-kmer fix-up of sub-k queries lives): every occurrence a plain scan of the window finds must be
+        # reported, and nothing else inside it.  reread_ok proves the reported positions right; this proves none is missing
+        # there (a dropped run or position of the merge / level / largest-k paths would show).  numpy only: a rolling
+        # polynomial hash per query length, candidates confirmed letter by letter.
+        n_ = text_.size
+        lens = np.diff(qo_[:nv_ + 1]).astype(np.int64)
+        ok = True
+        for lo in sorted({0, max(0, n_ - W)}):
+            win = text_[lo:lo + W].astype(np.uint64)
+            for m_ in np.unique(lens):
+                m_ = int(m_)
+                if m_ == 0 or m_ > win.size:
+                    continue
+                qsel = np.nonzero(lens == m_)[0]
+                with np.errstate(over="ignore"):
+                    h = np.zeros(win.size - m_ + 1, np.uint64)
+                    for j in range(m_):
+                        h = h * np.uint64(1099511628211) + win[j:j + h.size]
+                    qh = np.zeros(qsel.size, np.uint64)
+                    for j in range(m_):
+                        qh = qh * np.uint64(1099511628211) + qr_[qo_[qsel].astype(np.int64) + j].astype(np.uint64)
+                order = np.argsort(qh, kind="stable")
+                qh_s = qh[order]
+                cand = np.nonzero(np.isin(h, qh_s))[0]                 # window offsets whose hash equals some query's
+                first = np.searchsorted(qh_s, h[cand], side="left")
+                last = np.searchsorted(qh_s, h[cand], side="right")
+                want = {int(q): [] for q in qsel}
+                for c, a, b in zip(cand.tolist(), first.tolist(), last.tolist()):
+                    for t in range(a, b):                               # (several of the first queries may be the same m-mer)
+                        q = int(qsel[order[t]])
+                        if np.array_equal(text_[lo + c:lo + c + m_], qr_[int(qo_[q]):int(qo_[q]) + m_]):
+                            want[q].append(lo + c)
+                for q in qsel.tolist():
+                    got = positions_[int(hit_off_[q]):int(hit_off_[q + 1])].astype(np.int64)
+                    got = got[(got >= lo) & (got + m_ <= lo + win.size)]
+                    ok &= bool(np.array_equal(got, np.asarray(want[q], np.int64)))
+        return bool(ok)
+
     # BASELINE configs[2..4] for the same K steps each, reported beside the headline (N = 1 only): own text, own index, the
     # same pipeline as `value`, checked by re-reading the first 2000 queries' positions and by the hit total of a second pass
     # A query length the configs do not hold, on an index that is already built: nq_p queries of m letters (half planted),
@@ -380,7 +421,7 @@ def worker(args):
         el_p, res_p, st_p = run_sharded(index, max(3, args.steps // 4), 1, True, 1, q_p)
         cn = res_p[0].counts()
         ho, po, _, _ = res_p[0].host(copy=False)
-        ok = reread_ok(text_, qr_p, qo_p, ho, po, min(2000, nq_p))
+        ok = reread_ok(text_, qr_p, qo_p, ho, po, min(2000, nq_p)) and windows_complete_ok(text_, sigma_, qr_p, qo_p, ho, po, min(500, nq_p))
         steps_p = max(3, args.steps // 4)
         o = {"M_queries_per_s": round(nq_p * steps_p / el_p / 1e6, 1), "G_hits_per_s": round(cn["n_hits"] * steps_p / el_p / 1e9, 1),
              "verified": bool(ok), "queries": nq_p,
@@ -401,6 +442,7 @@ def worker(args):
         cn = res_c[0].counts()
         ho, po, _, _ = res_c[0].host(copy=False)
         ok = reread_ok(text_c, qr_c, qo_c, ho, po, min(2000, nq_c)) and all(r_.counts()["n_hits"] == cn["n_hits"] for r_ in res_c)
+        ok = ok and windows_complete_ok(text_c, sg, qr_c, qo_c, ho, po, min(1000, nq_c))
         ms = el_c / args.steps * 1e3
         fill_c = st_c.get("k_fill", {"launches": 0, "total_ms": 0.0})
         f_ms = fill_c["total_ms"] / max(fill_c["launches"], 1)
@@ -413,6 +455,12 @@ def worker(args):
              "workload": f"BASELINE configs[{cfg - 1}]: sigma={sg} text {n_c}, ks={ks_c}, lengths {ql_c}, planted {pl_c}", "wall_s": None}
         for r_ in res_c:
             r_.close()
+        if not args.no_two_streams:
+            el2, res2c, _ = run_sharded(idx_c, args.steps, args.warmup, False, 2, q_c)
+            o["two_streams"] = {"value": round(nq_c * args.steps / el2 / 1e6, 3), "ms_per_step": round(el2 / args.steps * 1e3, 4),
+                                "same_hit_total": bool(res2c[0].counts()["n_hits"] == cn["n_hits"])}
+            for r_ in res2c:
+                r_.close()
         if cfg == 3:                                                   # sub-k queries and short reads on the multi-k index
             o["length_probes"] = {f"m={m_}": length_probe(idx_c, text_c, sg, m_, nq_p) for m_, nq_p in ((6, 50_000), (7, 200_000), (13, 500_000), (16, 500_000))}
         idx_c.close()
@@ -501,40 +549,55 @@ def worker(args):
             T = args.cpu_threads or max(1, min(16, usable))
             oidx = orc.Index(text, args.sigma, ks, n_threads=T)
             log(f"oracle (CPU restatement) index built in {time.time() - t1:.1f}s")
+            # SURVEY 8d / BASELINE.md 3: one warm-up pass, then >= 5 timed passes; the MEDIAN is the value, min / max beside it.
+            # The sample keeps a leg under ~10 s of wall: ns queries on T threads, n1 on one.
             ns = min(args.cpu_sample, nq)
             ref_pool = orc.ref_lib() is not None and hasattr(orc.ref_lib(), "ref_pool_run")   # the REFERENCE's thread_pool.cpp, built in oracle/_ref
-            t1 = time.perf_counter()
-            oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=T, keep_hits=False, reference_pool=ref_pool)
-            dt = time.perf_counter() - t1
+            n_pass = max(5, args.cpu_passes)
+
+            def cpu_leg(n_q, threads, pool):
+                def one():
+                    t0 = time.perf_counter()
+                    oidx.search_batch(qr_host[:n_q * m], qoff_host[:n_q + 1], n_threads=threads, keep_hits=False, reference_pool=pool)
+                    return time.perf_counter() - t0
+                warm = one()
+                # (a first pass far slower than the budget: fewer queries per pass, still >= 5 passes)
+                while warm * (n_pass + 1) > 12.0 and n_q > 200_000:
+                    n_q //= 2
+                    warm = one()
+                ts = sorted(one() for _ in range(n_pass))
+                rates = [n_q / t / 1e6 for t in ts]
+                return {"value": round(float(np.median(rates)), 4), "min": round(min(rates), 4), "max": round(max(rates), 4), "passes": n_pass,
+                        "queries_per_pass": n_q, "wall_s": round(sum(ts) + warm, 1)}
+
+            leg_T = cpu_leg(ns, T, ref_pool)
             # "T = hardware_concurrency, also T = 1" — the same sample on every usable core (chunked >= 4 T by the batch)
-            dt_all = None
+            leg_all = None
             if usable > T and not (quota_cores and quota_cores <= T + 0.5):      # (a quota of T cores: more threads only share them)
-                t1 = time.perf_counter()
-                oidx.search_batch(qr_host[:ns * m], qoff_host[:ns + 1], n_threads=usable, keep_hits=False, reference_pool=ref_pool)
-                dt_all = time.perf_counter() - t1
-            n1 = min(ns, 1_000_000)                               # the same restatement on one thread ("also T=1")
-            t1 = time.perf_counter()
-            oidx.search_batch(qr_host[:n1 * m], qoff_host[:n1 + 1], n_threads=1, keep_hits=False)
-            dt1 = time.perf_counter() - t1
+                leg_all = cpu_leg(ns, usable, ref_pool)
+            leg_1 = cpu_leg(min(ns, 1_000_000), 1, False)         # the same restatement on one thread ("also T=1")
             cpu_model = "unknown CPU"
             try:
                 with open("/proc/cpuinfo") as f:
                     cpu_model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
             except Exception:
                 pass
-            cpu_baseline = {"value": round(ns / dt / 1e6, 4), "unit": "M queries/s", "cores": T, "kind": "port",
-                            "sample": f"first {ns} of the {nq} queries, same 1e8-bp text, the restated search(q).to_vector() per query, tasks carried by "
+            cpu_baseline = {"value": leg_T["value"], "unit": "M queries/s", "cores": T, "kind": "port",
+                            "min": leg_T["min"], "max": leg_T["max"], "passes": leg_T["passes"],
+                            "sample": f"first {leg_T['queries_per_pass']} of the {nq} queries, same 1e8-bp text, the restated search(q).to_vector() per query, tasks carried by "
                                       + ("the reference's own thread_pool (thread_pool.{hpp,cpp} compiled from its sources into oracle/_ref)" if ref_pool
                                          else "the restated thread pool (oracle/_ref not built)")
-                                      + f" ({T} threads of {usable} usable, {cpu_model}; std::unordered_map buckets in place of robin_hood), {dt:.1f}s wall",
-                            "single_thread_value": round(n1 / dt1 / 1e6, 4), "single_thread_sample": f"first {n1} queries, {dt1:.1f}s",
-                            "all_cores_value": round(ns / dt_all / 1e6, 4) if dt_all else None, "all_cores": usable if dt_all else None,
-                            "all_cores_sample": (f"the same {ns} queries on all {usable} usable hardware threads, {dt_all:.1f}s wall"
-                                                 + (f"; the container's CPU quota is {quota_cores:.1f} cores, which is what this leg measures" if quota_cores else "; no CPU quota found (cgroup)")) if dt_all else None,
+                                      + f" ({T} threads of {usable} usable, {cpu_model}; std::unordered_map buckets in place of robin_hood); one warm-up pass, "
+                                        f"median of {leg_T['passes']} timed passes, {leg_T['wall_s']} s wall",
+                            "single_thread_value": leg_1["value"], "single_thread_min": leg_1["min"], "single_thread_max": leg_1["max"],
+                            "single_thread_sample": f"first {leg_1['queries_per_pass']} queries, one warm-up pass, median of {leg_1['passes']} timed passes, {leg_1['wall_s']} s wall",
+                            "all_cores_value": leg_all["value"] if leg_all else None, "all_cores": usable if leg_all else None,
+                            "all_cores_min": leg_all["min"] if leg_all else None, "all_cores_max": leg_all["max"] if leg_all else None,
+                            "all_cores_sample": (f"the same {leg_all['queries_per_pass']} queries on all {usable} usable hardware threads, median of {leg_all['passes']} passes, {leg_all['wall_s']} s wall"
+                                                 + (f"; the container's CPU quota is {quota_cores:.1f} cores, which is what this leg measures" if quota_cores else "; no CPU quota found (cgroup)")) if leg_all else None,
                             "cpu_quota_cores": quota_cores,
-                            "all_cores_skipped": (f"the container's CPU quota is {quota_cores:.1f} cores: {usable} threads would only share them "
-                                                  f"(measured once: 11.2-11.7 M queries/s on 256 threads against 11.6-14.6 on 16, BASELINE.md)")
-                                                 if (dt_all is None and quota_cores and usable > T) else None}
+                            "all_cores_skipped": (f"the container's CPU quota is {quota_cores:.1f} cores: {usable} threads would only share them")
+                                                 if (leg_all is None and quota_cores and usable > T) else None}
             o_off, o_pos, o_st, _ = oidx.search_batch(qr_host[:nv * m], qoff_host[:nv + 1], n_threads=T)
             verified = bool(np.array_equal(o_off, hit_off[:nv + 1]) and np.array_equal(o_pos, positions[:int(hit_off[nv])]))
             oidx.close()

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define KMX_VERSION 3
+#define KMX_VERSION 4
 #define KMX_MAX_KS 32               /* number of k values one index may hold                      */
 #define KMX_MAX_DEVICES 16          /* replicas of one index (one per GPU of a node)              */
 #define KMX_QUERY_SIZE_RANGE 10000  /* kmer_index::_query_size_range, kmer_index.hpp:401          */
@@ -105,7 +105,9 @@ typedef struct kmx_options {
                                   query, and shorter ones merge sigma^L times fewer lists.  Results are identical; each level costs
                                   one more copy of the position array (4 bytes x text length) and is left out when it does not
                                   fit.  0 = default (KMX_PREFIX_LEVELS in the environment, else 2), -1 = none, N = at most N
-                                  (<= 3).  Levels are derived data: not part of the on-disk image, rebuilt by kmx_index_load. */
+                                  (<= 3).  Levels are derived data: not part of the on-disk image, rebuilt by kmx_index_load.
+                                  A caller compiled against KMX_VERSION 1 or 2 (shorter struct_size: it cannot say what it
+                                  wants) gets none.  kmx_index_levels reports what was built, kmx_index_memory what it costs. */
 } kmx_options;
 
 /* kmx_search_batch flags */
@@ -252,6 +254,18 @@ kmx_status kmx_result_part_view_device(const kmx_result* r, uint32_t part, int32
 /* The devices an index is replicated on (devices[] holds KMX_MAX_DEVICES entries). */
 kmx_status kmx_index_devices(const kmx_index* index, uint32_t* n_devices, int32_t* devices);
 
+/* The exchange step of SURVEY 8e behind the C-ABI ("hit lists gathered ... over xGMI"): the parts of a multi-device result
+ * gathered into ONE set of device arrays in the HBM of `dst_device` (any device of the node; normally the first replica's):
+ * every part's hit lists go device to device (hipMemcpyPeerAsync on the part's own stream — all links at once, each behind
+ * its part's last kernel) to the displacement the parts in front of it leave, its hit_off entries are rebased by that
+ * displacement on the destination, its statuses follow.  What arrives is byte for byte what one device returns for the whole
+ * batch: d_hit_off[nq + 1] (global), d_positions[n_hits], d_status[nq].  The arrays belong to the result (freed with it,
+ * reused by the next gather into it) and are complete when the call returns.  A single-part result on dst_device is
+ * returned where it lies (no copy).  Refused for chunk-streamed results (they live in host memory) and COUNT_ONLY
+ * searches have no positions (d_positions = NULL). */
+kmx_status kmx_result_gather_device(kmx_result* r, int32_t dst_device, const uint64_t** d_hit_off, const uint32_t** d_positions,
+                                    const uint8_t** d_status);
+
 /* KMX_SEARCH_KEEP_MASKS only — the reference's zero-copy result view
  * (kmer_index_result.hpp:15-24: pointers to bucket vectors + a compressed_bitset).
  * For a STITCH query q (kinds[q] == KMX_KIND_STITCH):
@@ -266,6 +280,20 @@ kmx_status kmx_index_devices(const kmx_index* index, uint32_t* n_devices, int32_
 kmx_status kmx_result_masks(kmx_result* r, const uint64_t** mask_base, const uint64_t** mask_words,
                             const uint32_t** cand_count, const uint64_t** cand_src);
 kmx_status kmx_index_arena_host(const kmx_index* index, const uint32_t** arena, uint64_t* n_elems);
+
+/* kmer_index_element<alphabet_t, position_t, k>::search_k(iterator) (kmer_index.hpp:183-190) = at(hash(it)) (:56-84): the
+ * bucket of ONE k-mer, as a borrowed window into the index's host arena — no device round trip, nothing to free; valid as
+ * long as the index.  `ranks` holds the k letters; *positions / *count receive the ascending text offsets of that k-mer,
+ * NULL / 0 when the text does not hold it (the reference's nullptr).  Needs keep_host_arena; the element's offset table
+ * (dense: 4 bytes per key; open addressing: 12 bytes per distinct key) is mirrored to host memory by the first call that
+ * asks for that k.  Callable from several threads at once.  KMX_ERR_INVALID_ARGUMENT: no element for this k, a letter
+ * outside the alphabet, an index without host arena. */
+kmx_status kmx_index_bucket_host(const kmx_index* index, uint32_t k, const uint8_t* ranks, const uint32_t** positions,
+                                 uint32_t* count);
+
+/* Prefix levels actually built (kmx_options::prefix_levels asks, memory and the planner decide): levels[i] = number of levels
+ * of the element of ks[i] (kmx_index_info's order), 0 for elements without.  levels holds KMX_MAX_KS entries. */
+kmx_status kmx_index_levels(const kmx_index* index, uint32_t* levels);
 
 void kmx_result_free(kmx_result* r);
 

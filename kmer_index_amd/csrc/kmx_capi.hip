@@ -192,8 +192,19 @@ struct kmx_index {
     KmxIndexDev h_header{};              // host copy of the device header (holds device pointers)
     kmx::FillVariant fill_variant{12, true};   // 3072-slot tiles (12 gathers in flight per thread), non-temporal stores
     bool rec32 = true;                   // every arena index fits 31 bits
+    bool broken = false;                 // a failed kmx_index_extend_query_size_range left the replicas' planner tables inconsistent
     std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
     Stats stats;
+    // kmx_index_bucket_host: host mirror of one element's offset table (dense: offs; open: the sorted distinct keys + offs),
+    // downloaded by the first call that asks for that k
+    struct HostDir {
+        std::once_flag once;
+        kmx_status st = KMX_OK;
+        std::string err;
+        std::vector<uint32_t> offs;
+        std::vector<uint64_t> ukeys;
+    };
+    std::unique_ptr<HostDir[]> host_dirs;
     std::vector<kmx_index*> peers;      // replicas 1..N-1 of a multi-device index (owned by replica 0, which is this object)
     size_t n_replicas() const { return 1 + peers.size(); }
     kmx_index* replica(size_t i) { return i ? peers[i - 1] : this; }
@@ -219,7 +230,7 @@ struct kmx_result {
     uint64_t nq = 0, n_hits = 0, n_exact = 0, n_stitch = 0, n_prefix = 0, n_error = 0, n_none = 0;
     uint64_t n_mask_words = 0;
     // device
-    DevBuf src, cnt, c0, aux, key, p1, kind, status, stitch_list, prefix_list, hit_off, bsum, ctr, tile_q, out,
+    DevBuf src, cnt, c0, aux, key, p1, kind, status, stitch_list, prefix_list, short_list, hit_off, bsum, ctr, tile_q, out,
         mask_words, stitch_hits, plen, poff, ptmp, in_qranks, in_qoff;
     unsigned long long* h_ctr = nullptr;   // pinned
     // host mirrors
@@ -251,11 +262,15 @@ struct kmx_result {
     bool host_chunk = false;               // (part) lives in host memory only
     kmx_result* worker = nullptr;
     kmx_result* worker2 = nullptr;         // ... and a second one: chunk i's results leave for the host while chunk i + 1 is searched
+    // kmx_result_gather_device: the parts of a multi-device result gathered into one set of arrays on gather_device
+    DevBuf g_hit_off, g_out, g_status;
+    int gather_device = -1;
+    hipStream_t gather_stream = nullptr;
 
     size_t device_bytes() const
     {
         size_t b = 0;
-        for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
+        for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &short_list, &hit_off, &bsum, &ctr,
                                 &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff, &small_xchg})
             b += d->cap;
         return b;
@@ -263,7 +278,7 @@ struct kmx_result {
 
     void release()
     {
-        for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &hit_off, &bsum, &ctr,
+        for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &short_list, &hit_off, &bsum, &ctr,
                           &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &in_qranks, &in_qoff, &small_xchg})
             b->release();
         for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox, &small_in})
@@ -274,6 +289,16 @@ struct kmx_result {
         done = nullptr;
         if (own_stream) (void)hipStreamDestroy(own_stream);
         own_stream = nullptr;
+        if (gather_device >= 0) {
+            int cur = 0;
+            const bool have = hipGetDevice(&cur) == hipSuccess;
+            (void)hipSetDevice(gather_device);
+            g_hit_off.release(); g_out.release(); g_status.release();
+            if (gather_stream) (void)hipStreamDestroy(gather_stream);
+            gather_stream = nullptr;
+            gather_device = -1;
+            if (have) (void)hipSetDevice(cur);
+        }
     }
 };
 
@@ -551,6 +576,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
         base += im.region;
         im = kmx::ElemImage();   // release host memory early
     }
+    ix->host_dirs.reset(new kmx_index::HostDir[n_ks]);
     ix->tail.assign(tail_kmax, tail_kmax + kmax);
     if ((st = upload(ix, tail_kmax, kmax, &h.tail)) != KMX_OK) return bail(st);
     {
@@ -818,6 +844,7 @@ static bool read_options(const kmx_options* opts, kmx_options& o)
     memcpy(&o, opts, opts->struct_size);
     o.struct_size = sizeof(kmx_options);
     if (opts->struct_size == v1) o.n_devices = 1;          // a version-1 caller: one replica, no environment override
+    if (opts->struct_size != sizeof(kmx_options)) o.prefix_levels = -1;   // a caller that cannot ask for prefix levels does not pay their HBM
     return true;
 }
 
@@ -881,7 +908,9 @@ kmx_status kmx_plan_engine(const uint32_t* ks, uint32_t n_ks, uint32_t range, ui
         if (ks[i] == 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_plan_engine: k must be > 0");
     const std::vector<uint32_t> v(ks, ks + n_ks);
     const std::vector<KmxPlanEntry> fast = kmx::make_fast_plan_entries(v, range, sigma);
-    for (uint32_t q = 0; q < range; ++q) k_used[q] = (q && fast[q].scheme == KMX_SCHEME_SINGLE) ? v[fast[q].elem] : 0u;
+    for (uint32_t q = 0; q < range; ++q)
+        k_used[q] = !q ? 0u : fast[q].scheme == KMX_SCHEME_SINGLE ? v[fast[q].elem]
+                  : fast[q].scheme == KMX_SCHEME_REPLANNED ? v[fast[q].nparts >> KMX_PLAN_ALT_SHIFT] : 0u;
     return KMX_OK;
 }
 
@@ -1220,23 +1249,46 @@ kmx_status kmx_index_extend_query_size_range(kmx_index* ix, uint32_t new_maximum
         if (st == KMX_OK && all[i]->d_index_fast) st = upload(all[i], fast.data(), fast.size(), &d_fast[i]);
         if (st != KMX_OK) { restore(); return st; }
     }
+    // commit: every replica's two headers around the new tables (the old tables stay allocated until the index is freed).  A
+    // publication that fails part-way (replica i) is undone on EVERY replica already switched, replica i's device copies
+    // included; if that cannot be done either, the index is marked unusable: shards of one batch must never classify a
+    // length differently.
     kmx_status st = KMX_OK;
-    for (size_t i = 0; i < all.size() && st == KMX_OK; ++i) {
+    struct Saved { KmxIndexDev header; const KmxPlanEntry* fast; uint32_t range; };
+    std::vector<Saved> saved;
+    for (kmx_index* r : all) saved.push_back({r->h_header, r->d_plan_fast, r->range});
+    size_t switched = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
         kmx_index* r = all[i];
         hipError_t e = hipSetDevice(r->device);
-        // both headers around the new tables (the old tables stay allocated until the index is freed)
-        const KmxIndexDev keep = r->h_header;
-        const KmxPlanEntry* keep_fast = r->d_plan_fast;
         r->h_header.plan = d_plans[i];
         r->h_header.range = new_maximum;
         if (d_fast[i]) r->d_plan_fast = d_fast[i];
+        r->range = new_maximum;
+        switched = i + 1;
         if (e == hipSuccess) e = publish_headers(r);
         if (e != hipSuccess) {
-            r->h_header = keep; r->d_plan_fast = keep_fast;
             st = fail(KMX_ERR_HIP, std::string("kmx_index_extend_query_size_range: ") + hipGetErrorString(e));
             break;
         }
-        r->range = new_maximum;
+    }
+    if (st != KMX_OK) {
+        const std::string first_err = g_err;
+        bool undone = true;
+        for (size_t j = 0; j < switched; ++j) {
+            kmx_index* r = all[j];
+            r->h_header = saved[j].header; r->d_plan_fast = saved[j].fast; r->range = saved[j].range;
+            (void)hipGetLastError();
+            hipError_t e = hipSetDevice(r->device);
+            if (e == hipSuccess) e = publish_headers(r);
+            if (e != hipSuccess) undone = false;
+        }
+        if (!undone) {
+            ix->broken = true;
+            restore();
+            return fail(KMX_ERR_HIP, first_err + "; the previous planner tables could not be restored on every replica: the index is unusable");
+        }
+        g_err = first_err;
     }
     restore();
     return st;
@@ -1248,6 +1300,62 @@ kmx_status kmx_index_arena_host(const kmx_index* ix, const uint32_t** arena, uin
     if (ix->host_arena.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "index was built without keep_host_arena");
     *arena = ix->host_arena.data();
     if (n_elems) *n_elems = ix->host_arena.size();
+    return KMX_OK;
+}
+
+kmx_status kmx_index_bucket_host(const kmx_index* cix, uint32_t k, const uint8_t* ranks, const uint32_t** positions, uint32_t* count)
+{
+    if (!cix || !ranks || !positions || !count) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_bucket_host: NULL argument");
+    *positions = nullptr; *count = 0;
+    kmx_index* ix = const_cast<kmx_index*>(cix);
+    if (ix->host_arena.empty()) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_bucket_host: index was built without keep_host_arena");
+    size_t e = 0;
+    while (e < ix->ks.size() && ix->ks[e] != k) ++e;
+    if (e == ix->ks.size() || !ix->host_dirs) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_bucket_host: the index holds no element for k = " + std::to_string(k));
+    uint64_t h = 0;                                              // rank-hash, kmer_index.hpp:56-73 (Horner: no wrap for a valid k)
+    for (uint32_t i = 0; i < k; ++i) {
+        if (ranks[i] >= ix->sigma) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_bucket_host: a letter outside the alphabet");
+        h = h * ix->sigma + ranks[i];
+    }
+    const KmxElemDev& el = ix->h_header.elems[e];
+    kmx_index::HostDir& hd = ix->host_dirs[e];
+    std::call_once(hd.once, [&] {
+        // one download per element and index: the table the device probes, as the host's directory
+        int cur = 0;
+        const bool have = hipGetDevice(&cur) == hipSuccess;
+        hipError_t he = hipSetDevice(ix->device);
+        try {
+            hd.offs.resize(ix->elem_sizes[e].n_offs);
+            if (el.table_kind == KMX_TABLE_OPEN) hd.ukeys.resize(ix->elem_sizes[e].n_ukeys);
+        } catch (const std::bad_alloc&) {
+            hd.st = KMX_ERR_OUT_OF_MEMORY; hd.err = "kmx_index_bucket_host: host allocation failed";
+        }
+        if (hd.st == KMX_OK) {
+            if (he == hipSuccess && !hd.offs.empty()) he = hipMemcpy(hd.offs.data(), el.offs, hd.offs.size() * 4, hipMemcpyDeviceToHost);
+            if (he == hipSuccess && !hd.ukeys.empty()) he = hipMemcpy(hd.ukeys.data(), el.ukeys, hd.ukeys.size() * 8, hipMemcpyDeviceToHost);
+            if (he != hipSuccess) { hd.st = KMX_ERR_HIP; hd.err = std::string("kmx_index_bucket_host: table download: ") + hipGetErrorString(he); }
+        }
+        if (have) (void)hipSetDevice(cur);
+    });
+    if (hd.st != KMX_OK) return fail(hd.st, hd.err);
+    uint64_t g = h;                                              // index of the key's group in offs
+    if (el.table_kind == KMX_TABLE_OPEN) {
+        const auto it = std::lower_bound(hd.ukeys.begin(), hd.ukeys.end(), h);
+        if (it == hd.ukeys.end() || *it != h) return KMX_OK;     // at(hash) == nullptr, kmer_index.hpp:76-84
+        g = uint64_t(it - hd.ukeys.begin());
+    }
+    if (g + 1 >= hd.offs.size()) return KMX_OK;
+    const uint32_t a = hd.offs[g], b = hd.offs[g + 1];
+    if (b == a) return KMX_OK;
+    *positions = ix->host_arena.data() + el.arena_base + a;      // the contiguous copy of the groups
+    *count = b - a;
+    return KMX_OK;
+}
+
+kmx_status kmx_index_levels(const kmx_index* ix, uint32_t* levels)
+{
+    if (!ix || !levels) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_index_levels: NULL argument");
+    for (size_t i = 0; i < ix->ks.size(); ++i) levels[i] = ix->h_header.elems[i].n_levels;
     return KMX_OK;
 }
 
@@ -1308,6 +1416,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     if (nq && (!d_qranks || !d_qoff)) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: NULL query buffers");
     if (nq >= 0xFFFFFFFFull) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch_device: at most 2^32-2 queries per batch");
     kmx_index* ix = const_cast<kmx_index*>(cix);
+    if (ix->broken) return fail(KMX_ERR_HIP, "the index is unusable: a failed kmx_index_extend_query_size_range left its replicas inconsistent");
     if (!ix->peers.empty() && nq) {
         // several replicas: the one that lives where the queries are
         hipPointerAttribute_t attr{};
@@ -1355,6 +1464,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->status.ensure(nq));
     HIP_TRY(r->stitch_list.ensure(nq * 4));
     HIP_TRY(r->prefix_list.ensure(nq * 4));
+    HIP_TRY(r->short_list.ensure(nq * 4));
     HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(nq), kmx::lookup_blocks(nq)) * 8));
     if (r->ctr.cap < 2 * KMX_CTR_COUNT * sizeof(unsigned long long)) {
         // two counter blocks per handle, used in turn: the scan of a batch zeroes the block of the next one
@@ -1365,7 +1475,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     }
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
-                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
+                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), r->short_list.as<uint32_t>(), nullptr};
     // this batch's counter block, and the one of the next batch on this handle
     if (!r->ctr_clean) {                                        // (after a batch whose scan did not reset it: the stream does)
         HIP_TRY(hipMemsetAsync(r->ctr.p, 0, 2 * KMX_CTR_COUNT * sizeof(unsigned long long), s));
@@ -1442,7 +1552,7 @@ static kmx_status search_finish(kmx_result* r)
     else HIP_TRY(hipStreamSynchronize(s));
     kmx::QueryDesc d{r->src.as<uint64_t>(), r->cnt.as<uint32_t>(), r->c0.as<uint32_t>(), r->aux.as<uint64_t>(),
                      r->key.as<uint64_t>(), r->p1.as<uint64_t>(), r->kind.as<uint8_t>(), r->status.as<uint8_t>(),
-                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), nullptr};
+                     r->stitch_list.as<uint32_t>(), r->prefix_list.as<uint32_t>(), r->short_list.as<uint32_t>(), nullptr};
     auto* ctr = r->ctr.as<unsigned long long>() + r->ctr_phase * KMX_CTR_COUNT;     // the counter block this search counts into
     const KmxIndexDev* dix = header_for(ix, flags);
     const kmx::FillVariant fv = kmx::effective_fill_variant(ix->fill_variant, ix->rec32);
@@ -1454,7 +1564,8 @@ static kmx_status search_finish(kmx_result* r)
         });
     };
     const uint64_t n_stitch_groups = r->h_ctr[KMX_CTR_STITCH], n_stitch_tiny = r->h_ctr[KMX_CTR_STITCH_TINY];   // front / back of stitch_list
-    const uint64_t n_stitch_pending = n_stitch_groups + n_stitch_tiny;                                  // still to be validated
+    const uint64_t n_stitch_short = r->h_ctr[KMX_CTR_STITCH_SHORT];                                     // short_list
+    const uint64_t n_stitch_pending = n_stitch_groups + n_stitch_tiny + n_stitch_short;                 // still to be validated
     r->n_stitch = n_stitch_pending + r->h_ctr[KMX_CTR_STITCH_RESOLVED];                                  // (k_lookup resolved the others itself)
     r->last_had_stitch = n_stitch_pending != 0;
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
@@ -1477,7 +1588,7 @@ static kmx_status search_finish(kmx_result* r)
             (void)hipGetLastError();
         timed(ix, K_VALIDATE, s, [&] {
             kmx::launch_validate(s, dix, ix->d_arena, qr, qo, d, n_stitch_groups, n_more, n_stitch_tiny, d.stitch_list + (nq - n_stitch_tiny),
-                                 r->mask_words.as<uint64_t>());
+                                 n_stitch_short, r->mask_words.as<uint64_t>(), !(flags & KMX_SEARCH_KEEP_MASKS));
         });
         scan_hits();
         HIP_TRY(hipMemcpyAsync(r->h_ctr, ctr, KMX_CTR_COUNT * sizeof(unsigned long long), hipMemcpyDeviceToHost, s));
@@ -1509,6 +1620,11 @@ static kmx_status search_finish(kmx_result* r)
                 kmx::QueryDesc dt = d;
                 dt.stitch_list = d.stitch_list + (nq - n_stitch_tiny);
                 kmx::launch_compact(s, ix->d_arena, dt, n_stitch_tiny, r->mask_words.as<uint64_t>(), hit_off, out);
+            }
+            if (n_stitch_short) {
+                kmx::QueryDesc dt = d;
+                dt.stitch_list = d.short_list;
+                kmx::launch_compact(s, ix->d_arena, dt, n_stitch_short, r->mask_words.as<uint64_t>(), hit_off, out);
             }
         });
 
@@ -1749,19 +1865,34 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
         }
     };
     int turn = 0;
+    bool single_worker = false;                               // after an out-of-memory: ONE set of device buffers from there on
+    static const long long inject_oom = getenv("KMX_TEST_INJECT_CHUNK_OOM") ? atoll(getenv("KMX_TEST_INJECT_CHUNK_OOM")) : 0;   // (test hook: the n-th chunk search reports out of memory)
+    long long n_searches = 0;
     uint64_t h0 = 0;                                          // hits of the chunks in front
     for (uint64_t q0 = 0; q0 < nq;) {
         const uint64_t q1 = std::min(nq, q0 + chunk_q);
         kmx_result*& wr = turn ? parent->worker2 : parent->worker;
         kmx_status st = join(turn);                          // the worker's previous chunk has left it
         if (st != KMX_OK) return finish(st);
-        st = search_host_one(ix, qranks, qoff, q0, q1, flags, &wr, true);
-        if (st == KMX_ERR_OUT_OF_MEMORY && chunk_q > 1024) {
-            // smaller chunks, and no second set of device buffers from here on if that is what did not fit
-            chunk_q /= 2; (void)hipGetLastError();
-            const kmx_status js = join(turn ^ 1);
-            if (js != KMX_OK) return finish(js);
-            if (turn && parent->worker2) { kmx_result_free(parent->worker2); parent->worker2 = nullptr; turn = 0; }
+        st = (inject_oom && ++n_searches == inject_oom) ? fail(KMX_ERR_OUT_OF_MEMORY, "kmx_search_batch: injected out-of-memory (KMX_TEST_INJECT_CHUNK_OOM)")
+                                                        : search_host_one(ix, qranks, qoff, q0, q1, flags, &wr, true);
+        if (st == KMX_ERR_OUT_OF_MEMORY && (chunk_q > 1024 || !single_worker)) {
+            // Out of device memory.  First the second set of device buffers goes (both copy tasks joined, worker2 released whichever
+            // worker was being searched into: its grow-only buffers from the larger chunks would starve the retry) and the SAME chunk
+            // size is tried with one worker; only if one worker alone does not fit either are the chunks halved.
+            (void)hipGetLastError();
+            const kmx_status js = finish(KMX_OK);
+            if (js != KMX_OK) return js;
+            if (single_worker) chunk_q = std::max<uint64_t>(chunk_q / 2, 1024);
+            single_worker = true;
+            if (parent->worker2) { kmx_result_free(parent->worker2); parent->worker2 = nullptr; }
+            turn = 0;
+            {
+                // results parked in the pool hold device memory too
+                std::vector<kmx_result*> idle;
+                { std::lock_guard<std::mutex> lock(ix->pool->mu); idle.swap(ix->pool->idle); }
+                for (kmx_result* r : idle) { r->release(); delete r; }
+            }
             continue;
         }
         if (st != KMX_OK) return finish(st);
@@ -1835,7 +1966,7 @@ static kmx_status search_host_chunked(kmx_index* ix, const uint8_t* qranks, cons
         }
         h0 += w->n_hits;
         q0 = q1;
-        turn ^= 1;
+        if (!single_worker) turn ^= 1;                       // (one worker: its copy task is joined at the top of the loop before it is searched into again)
     }
     const kmx_status fs = finish(KMX_OK);
     if (fs != KMX_OK) return fs;
@@ -1853,6 +1984,7 @@ kmx_status kmx_search_batch(const kmx_index* cix, const uint8_t* qranks, const u
         if (qoff[i + 1] < qoff[i]) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: qoff must be non-decreasing");
     if (nq && !qranks && qoff[nq] != 0) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: NULL query letters");   // (a batch of empty queries has none)
     kmx_index* ix = const_cast<kmx_index*>(cix);
+    if (ix->broken) return fail(KMX_ERR_HIP, "the index is unusable: a failed kmx_index_extend_query_size_range left its replicas inconsistent");
     const size_t W = ix->n_replicas();
     if (W == 1) {
         if (*out && !(*out)->parts.empty() && !(*out)->chunked) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_search_batch: the result handle belongs to a multi-device search");
@@ -1989,6 +2121,87 @@ kmx_status kmx_result_view_device(const kmx_result* r, const uint64_t** d_hit_of
     if (d_positions) *d_positions = r->out.as<uint32_t>();
     if (d_status) *d_status = r->status.as<uint8_t>();
     return KMX_OK;
+}
+
+kmx_status kmx_result_gather_device(kmx_result* r, int32_t dst_device, const uint64_t** d_hit_off, const uint32_t** d_positions,
+                                    const uint8_t** d_status)
+{
+    if (!r) return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_gather_device: result is NULL");
+    if (r->chunked || r->host_chunk)
+        return fail(KMX_ERR_INVALID_ARGUMENT, "kmx_result_gather_device: the batch was streamed through the device in chunks: its result lives in host memory only");
+    int n_dev = 0;
+    HIP_TRY(hipGetDeviceCount(&n_dev));
+    if (dst_device < 0 || dst_device >= n_dev) return fail(KMX_ERR_NO_DEVICE, "kmx_result_gather_device: no such device");
+    if (r->ctx.pending) { kmx_status fs = search_finish(r); if (fs != KMX_OK) return fs; }
+    if (r->parts.empty() && r->device == dst_device) return kmx_result_view_device(r, d_hit_off, d_positions, d_status);   // already there
+    int caller_device = 0;
+    (void)hipGetDevice(&caller_device);
+    struct Part { const kmx_result* p; uint64_t q0, nq; const uint64_t* ho; const uint32_t* pos; const uint8_t* st; hipEvent_t ev; };
+    std::vector<Part> parts;
+    auto leave = [&](kmx_status st) {
+        for (Part& pt : parts) if (pt.ev) (void)hipEventDestroy(pt.ev);
+        (void)hipSetDevice(caller_device);
+        return st;
+    };
+    const size_t n_parts = r->parts.empty() ? 1 : r->parts.size();
+    for (size_t i = 0; i < n_parts; ++i) {
+        kmx_result* p = r->parts.empty() ? r : r->parts[i];
+        const uint64_t q0 = r->parts.empty() ? 0 : r->part_q0[i], q1 = r->parts.empty() ? r->nq : r->part_q0[i + 1];
+        if (!p || q1 == q0) continue;
+        Part pt{p, q0, q1 - q0, nullptr, nullptr, nullptr, nullptr};
+        const kmx_status st = kmx_result_view_device(p, &pt.ho, &pt.pos, &pt.st);     // (completes the part; a latency-path part is re-run on the device)
+        if (st != KMX_OK) return leave(st);
+        parts.push_back(pt);
+    }
+    const bool want_pos = !(r->flags & KMX_SEARCH_COUNT_ONLY) && r->n_hits;
+    hipError_t e = hipSetDevice(dst_device);
+    if (e == hipSuccess && r->gather_device >= 0 && r->gather_device != dst_device) {
+        // (buffers of an earlier gather to another device)
+        (void)hipSetDevice(r->gather_device);
+        r->g_hit_off.release(); r->g_out.release(); r->g_status.release();
+        if (r->gather_stream) (void)hipStreamDestroy(r->gather_stream);
+        r->gather_stream = nullptr;
+        e = hipSetDevice(dst_device);
+    }
+    r->gather_device = dst_device;
+    if (e == hipSuccess && !r->gather_stream) e = hipStreamCreateWithFlags(&r->gather_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = r->g_hit_off.ensure((r->nq + 1) * 8);
+    if (e == hipSuccess) e = r->g_status.ensure(std::max<uint64_t>(r->nq, 1));
+    if (e == hipSuccess && want_pos) e = r->g_out.ensure(r->n_hits * 4);
+    if (e != hipSuccess) return leave(fail(e == hipErrorOutOfMemory ? KMX_ERR_OUT_OF_MEMORY : KMX_ERR_HIP, std::string("kmx_result_gather_device: ") + hipGetErrorString(e)));
+    uint64_t* g_off = r->g_hit_off.as<uint64_t>();
+    // every part leaves on its OWN stream (behind its last kernel) and over its own link ...
+    uint64_t h0 = 0;
+    std::vector<uint64_t> base;
+    for (Part& pt : parts) {
+        const kmx_result* p = pt.p;
+        base.push_back(h0);
+        e = hipSetDevice(p->device);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(g_off + pt.q0 + 1, dst_device, pt.ho + 1, p->device, pt.nq * 8, p->stream);
+        if (e == hipSuccess) e = hipMemcpyPeerAsync(r->g_status.as<uint8_t>() + pt.q0, dst_device, pt.st, p->device, pt.nq, p->stream);
+        if (e == hipSuccess && want_pos && p->n_hits)
+            e = hipMemcpyPeerAsync(r->g_out.as<uint32_t>() + h0, dst_device, pt.pos, p->device, p->n_hits * 4, p->stream);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&pt.ev, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(pt.ev, p->stream);
+        if (e != hipSuccess) return leave(fail(KMX_ERR_HIP, std::string("kmx_result_gather_device: part copy: ") + hipGetErrorString(e)));
+        h0 += p->n_hits;
+    }
+    // ... and the destination rebases each part's offsets behind the hits of the parts in front of it
+    e = hipSetDevice(dst_device);
+    if (e == hipSuccess) e = hipMemsetAsync(g_off, 0, 8, r->gather_stream);
+    for (size_t i = 0; i < parts.size() && e == hipSuccess; ++i) {
+        e = hipStreamWaitEvent(r->gather_stream, parts[i].ev, 0);
+        if (e == hipSuccess) {
+            kmx::launch_rebase_offsets(r->gather_stream, g_off + parts[i].q0 + 1, parts[i].nq, base[i]);
+            e = hipGetLastError();
+        }
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(r->gather_stream);
+    if (e != hipSuccess) return leave(fail(KMX_ERR_HIP, std::string("kmx_result_gather_device: ") + hipGetErrorString(e)));
+    if (d_hit_off) *d_hit_off = g_off;
+    if (d_positions) *d_positions = want_pos ? r->g_out.as<uint32_t>() : nullptr;
+    if (d_status) *d_status = r->g_status.as<uint8_t>();
+    return leave(KMX_OK);
 }
 
 kmx_status kmx_result_view(kmx_result* r, const uint64_t** hit_off, const uint32_t** positions, const uint8_t** status,

@@ -112,8 +112,8 @@ std::vector<KmxPlanEntry> make_plan_entries(const std::vector<uint32_t>& ks, uin
 // as long as those of k = 12 (two buckets of 1526 positions to intersect at 1e8 letters, against two of 6).  Which element
 // answers does not change WHAT is answered — every occurrence of the query, ascending — so for single-k entries with q > k the
 // device table names the LARGEST k <= q instead (shortest buckets), unless either choice could run into the sub-k fan-out guard
-// through its rest (:119-122 via :234: the status must stay the reference's).  Entries of the multi-k scheme, exact lengths and
-// sub-k lengths are the reference's.  Searches that expose the reference's result object (KMX_SEARCH_KEEP_MASKS: candidate run
+// through its rest (:119-122 via :234: the status must stay the reference's).  Sums of the multi-k scheme are re-planned the same
+// way (KMX_SCHEME_REPLANNED, below); exact lengths and sub-k lengths are the reference's.  Searches that expose the reference's result object (KMX_SEARCH_KEEP_MASKS: candidate run
 // + compressed_bitset of the element the REFERENCE would use) run on the reference's table.
 std::vector<KmxPlanEntry> make_fast_plan_entries(const std::vector<uint32_t>& ks, uint32_t range, uint32_t sigma)
 {
@@ -126,10 +126,27 @@ std::vector<KmxPlanEntry> make_fast_plan_entries(const std::vector<uint32_t>& ks
     };
     for (uint32_t q = 1; q < range; ++q) {
         KmxPlanEntry& e = out[q];
+        auto risky = [&](uint32_t k) { const uint32_t r = q % k; return r != 0 && fan_out(k - r); };
+        if (e.scheme == KMX_SCHEME_MULTI && e.nparts >= 2) {
+            // A sum of several ks (kmer_index.hpp:427-443) is also a run of parts of ONE k with the k-mer that ends the query as
+            // the last of them: on the LARGEST k of the index every bucket is the shortest the index has (20 letters on {8, 10, 12}:
+            // two 12-mers, 6 positions each at 1e8 letters, where the sum 10 + 10 intersects two buckets of 95).  The reference's
+            // entry stays in place — longer sums walk through it (elem = its last summand, nparts = their number) — and the
+            // element the engine uses instead rides in the upper bits of nparts.  Not when the rest could reach the fan-out guard
+            // (the multi-k scheme never throws there: the status must stay the reference's), not for sums too long to encode.
+            if (e.nparts > KMX_PLAN_NPARTS_MASK) continue;
+            uint32_t best_k = 0, best_i = 0;
+            for (size_t i = 0; i < ks.size(); ++i)
+                if (ks[i] < q && ks[i] > best_k && !risky(ks[i])) { best_k = ks[i]; best_i = uint32_t(i); }
+            if (best_k) {
+                e.scheme = KMX_SCHEME_REPLANNED;
+                e.nparts = uint16_t(e.nparts | (best_i << KMX_PLAN_ALT_SHIFT));
+            }
+            continue;
+        }
         if (e.scheme != KMX_SCHEME_SINGLE) continue;
         const uint32_t k0 = ks[e.elem];
         if (q <= k0) continue;
-        auto risky = [&](uint32_t k) { const uint32_t r = q % k; return r != 0 && fan_out(k - r); };
         if (risky(k0)) continue;
         uint32_t best_k = k0;
         for (size_t i = 0; i < ks.size(); ++i)

@@ -19,6 +19,7 @@ struct QueryDesc {
     uint8_t* status;        // kmx_query_status
     uint32_t* stitch_list;  // indices of the STITCH queries (arbitrary order)
     uint32_t* prefix_list;  // indices of the PREFIX queries (arbitrary order)
+    uint32_t* short_list;   // indices of the STITCH queries of the short class (KMX_VSHORT; k_validate_short), from its front
     uint32_t* stitch_hits;  // STITCH: surviving candidates of query q at [64 * aux[q], 64 * aux[q] + cnt[q]), written by
                             // k_validate and copied out by k_fill; nullptr -> k_compact decodes the masks instead
 };
@@ -27,7 +28,8 @@ uint64_t lookup_blocks(uint64_t nq);
 void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits, uint32_t flags);
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
-                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words);
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t n_short,
+                     uint64_t* mask_words, bool direct);   // direct: tiny queries whose survivors are one run of the first bucket leave as plain copies
 // the whole search of a small batch in one launch; `mailbox` is page-locked host memory (layout: kmx_types.h)
 // n_blocks workgroups; xchg: n_blocks zeroed u64 words of device memory (the workgroups' totals), may be NULL for one workgroup
 void launch_small(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, unsigned char* mailbox, const KmxSmallLayout& layout, uint32_t n_blocks,
@@ -107,5 +109,7 @@ uint64_t prefix_merge_tile();
 // prefix levels: the batch of all m-mers in rank-hash order (m * nq letters, nq + 1 offsets); 64-bit offsets as a 32-bit table
 void launch_all_kmers(hipStream_t s, uint32_t m, uint32_t sigma, uint64_t nq, uint8_t* d_qranks, uint64_t* d_qoff);
 void launch_narrow_offsets(hipStream_t s, const uint64_t* d_in, uint64_t n, uint32_t* d_out);
+// off[i] += add for i < n (kmx_result_gather_device: a part's hit_off entries behind the hits of the parts in front of it)
+void launch_rebase_offsets(hipStream_t s, uint64_t* d_off, uint64_t n, uint64_t add);
 
 } // namespace kmx

@@ -44,6 +44,12 @@
 #define KMX_PM_WAVE_PAD (KMX_PSORT_MAX_RUNS + KMX_PM_WAVE_EMAX + 5)   // sentinel cells + the reads of a chunk past its end
 #define KMX_PM_TILE 4096     // k_prefix_merge_pass: output positions per workgroup (divides KMX_PSORT_BLOCK_CAP)
 #define KMX_STAGE_CAP 1024   // k_validate: part-bucket entries staged in LDS per wave
+// k_validate: KMX_VGROUPS queries per wave, one per KMX_VGROUP-lane group
+#define KMX_VGROUP 16                            // 32 and 64 lanes per query measured slower
+#define KMX_VGROUPS (KMX_WAVE / KMX_VGROUP)
+#define KMX_VSLICES (64 / KMX_VGROUP)            // ballot slices per mask word
+#define KMX_VSTAGE (1024 / KMX_VGROUPS)          // staged bucket entries per group (4 KB of LDS per wave)
+#define KMX_VCH 8                                // candidates per lane and chunk, searched in lockstep
 
 namespace kmx {
 
@@ -57,7 +63,9 @@ namespace kmx {
 #define KMX_P1_MORE (uint64_t(1) << 63)    // QueryDesc::p1: the query has further parts beyond the one p1 names
 #define KMX_P1_BIG (uint64_t(1) << 62)     // the first part's bucket is long (a repeat of the text): k_validate leaves the
                                            // query to validate_big_wave, which anchors it on its smallest bucket
-#define KMX_P1_DELTA_MASK 0x3FFFFFFFu      // offset of the filter part in the query (bits 32..61 of p1)
+#define KMX_P1_SWAP (uint64_t(1) << 61)    // short class only (k_validate_short): the part p1 names has the SHORTER bucket — its entries
+                                           // are walked and looked up in the first part's bucket instead of the other way round
+#define KMX_P1_DELTA_MASK 0x1FFFFFFFu      // offset of the filter part in the query (bits 32..60 of p1)
 #define KMX_VBIG 1024                      // candidates beyond which a STITCH query counts as big
 // A filter bucket of more than 256 entries does not fit the stage of a 16-lane group in k_validate; up to KMX_VWIDE entries
 // the query gets a wave of its own with the whole stage (k_validate_wide) instead of searching the bucket where it lies.
@@ -94,15 +102,29 @@ typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 
-// plan[m] as one 32-bit load ({u8 scheme, u8 elem, u16 nparts}, little endian)
-__device__ __forceinline__ KmxPlanEntry load_plan(const KmxIndexDev* __restrict__ ix, uint64_t m)
+// plan[m] as one 32-bit load ({u8 scheme, u8 elem, u16 nparts}, little endian).
+// plan_effective: the entry a query of m letters is ANSWERED by — a KMX_SCHEME_REPLANNED entry (engine planner table) reads
+// as SINGLE on its alternative element; plan_chain: the entry as the reference's DP wrote it (elem = last summand), which is
+// what a walk over the summands of a longer sum wants (:434-435).
+__device__ __forceinline__ uint32_t plan_effective(uint32_t raw)
 {
-    const uint32_t raw = ((const KMX_GLOBAL uint32_t*)ix->plan)[m];
+    return (raw & 0xFF) == KMX_SCHEME_REPLANNED ? (uint32_t(KMX_SCHEME_SINGLE) | ((raw >> (16 + KMX_PLAN_ALT_SHIFT)) << 8) | (1u << 16)) : raw;
+}
+__device__ __forceinline__ KmxPlanEntry plan_unpack(uint32_t raw)
+{
     KmxPlanEntry e;
     e.scheme = uint8_t(raw & 0xFF);
     e.elem = uint8_t((raw >> 8) & 0xFF);
-    e.nparts = uint16_t(raw >> 16);
+    e.nparts = uint16_t((raw >> 16) & KMX_PLAN_NPARTS_MASK);
     return e;
+}
+__device__ __forceinline__ KmxPlanEntry load_plan(const KmxIndexDev* __restrict__ ix, uint64_t m)
+{
+    return plan_unpack(plan_effective(((const KMX_GLOBAL uint32_t*)ix->plan)[m]));
+}
+__device__ __forceinline__ KmxPlanEntry load_plan_chain(const KmxIndexDev* __restrict__ ix, uint64_t m)
+{
+    return plan_unpack(((const KMX_GLOBAL uint32_t*)ix->plan)[m]);
 }
 
 struct Run {
@@ -419,7 +441,7 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
             uint32_t extra_delta = 0;
             const uint32_t nparts = pe.nparts;
             for (uint32_t j = 0; j < nparts && all && ranks_ok; ++j) {
-                const KmxPlanEntry e = load_plan(ix, mm);
+                const KmxPlanEntry e = load_plan_chain(ix, mm);
                 const KmxElemDev* el = &elems_s[e.elem];
                 const uint32_t k = el->k;
                 mm -= k;                                  // this summand covers [mm, mm + k)
@@ -479,14 +501,79 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
-    unsigned int n_stitch, n_stitch_tiny, n_resolved, n_prefix, n_prefix_big, n_prefix_merge, n_prefix_mid, n_prefix_plain, n_error, n_none, n_more;
+    unsigned int n_stitch, n_stitch_tiny, n_stitch_short, n_resolved, n_prefix, n_prefix_big, n_prefix_merge, n_prefix_mid, n_prefix_plain, n_error, n_none, n_more;
     unsigned long long words, pelems, hits;
     unsigned int max_runs;
-    unsigned int base_stitch, base_stitch_tiny, base_prefix, base_prefix_big;
+    unsigned int base_stitch, base_stitch_tiny, base_stitch_short, base_prefix, base_prefix_big;
     unsigned long long base_words;
+    unsigned int max_fan_exp;       // largest j with sigma^j <= KMX_SUBK_FANOUT_LIMIT (the guard of kmer_index.hpp:119-122 as an exponent)
 };
 
-__global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restrict__ ix,
+// rank-hash (kmer_index.hpp:56-73) of the first `len` <= 16 letters of a 16-byte block that is already in registers
+__device__ __forceinline__ bool hash16(const u32x4_a1& w, uint32_t len, uint32_t sigma, uint64_t& h)
+{
+    uint64_t lo = uint64_t(w[0]) | (uint64_t(w[1]) << 32), hi = uint64_t(w[2]) | (uint64_t(w[3]) << 32);
+    uint64_t acc = 0;
+    bool ok = true;
+    for (uint32_t j = 0; j < len; ++j) {
+        const uint32_t r = uint32_t(lo & 0xFF);
+        lo = (lo >> 8) | (hi << 56);
+        hi >>= 8;
+        ok &= r < sigma;
+        acc = acc * sigma + r;
+    }
+    h = acc;
+    return ok;
+}
+// at(hash) (kmer_index.hpp:76-84) in two halves, so that the loads of several queries can be in flight together:
+// where the first 16 bytes of the probe lie — dense: the table entries of h (cnt8 / atab / offs); open: the home slot —
+__device__ __forceinline__ const char* probe_first_addr(const KmxElemDev* el, uint64_t h)
+{
+    if (el->table_kind == KMX_TABLE_DENSE)
+        return el->cnt8 ? reinterpret_cast<const char*>(el->cnt8 + (h & ~uint64_t(15)))      // the aligned 16 bytes holding cnt8[h]
+                        : reinterpret_cast<const char*>((el->atab ? el->atab : el->offs) + h);
+    return reinterpret_cast<const char*>(el->slots + slot_hash_dev(h, el->log2cap));
+}
+// ... and the bucket they name (linear probing continues from the prefetched slot)
+__device__ __forceinline__ Run probe_finish(const KmxElemDev* el, uint64_t h, const u32x4_a1& pr)
+{
+    Run r{0, 0};
+    if (el->table_kind == KMX_TABLE_DENSE) {
+        if (el->cnt8) {
+            const uint32_t b = uint32_t(h) & 15u;
+            const uint32_t wsel = (b >> 2) == 0 ? pr[0] : (b >> 2) == 1 ? pr[1] : (b >> 2) == 2 ? pr[2] : pr[3];
+            const uint32_t c = (wsel >> ((b & 3u) * 8u)) & 0xFFu;
+            if (c != 255u) { r.src = el->cell_base + (h << el->cell_shift); r.cnt = c; }
+            else {                                    // (rare) the group is longer than a cell: the contiguous copy
+                const KMX_GLOBAL uint32_t* offs = as_global(el->offs);
+                const uint32_t a = offs[h], e = offs[h + 1];
+                r.src = el->arena_base + a; r.cnt = e - a;
+            }
+        }
+        else if (el->atab) { r.src = el->arena_base + (pr[0] & ~31u); r.cnt = atab_count(pr[0], pr[1]); }
+        else { r.src = el->arena_base + pr[0]; r.cnt = pr[1] - pr[0]; }
+        return r;
+    }
+    const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);
+    const uint64_t mask = (uint64_t(1) << el->log2cap) - 1;
+    uint64_t s = slot_hash_dev(h, el->log2cap);
+    uint64_t key = uint64_t(pr[0]) | (uint64_t(pr[1]) << 32);
+    uint32_t off = pr[2], c = pr[3];
+    while (c != 0 && key != h) {
+        s = (s + 1) & mask;
+        const u64x2 raw = *(const KMX_GLOBAL u64x2*)(slots + s);
+        key = raw.x; off = uint32_t(raw.y); c = uint32_t(raw.y >> 32);
+    }
+    if (c) { r.src = el->arena_base + off; r.cnt = c; }
+    return r;
+}
+
+#define KMX_PLAN_LDS 256        // planner entries kept in LDS by k_lookup (queries shorter than this take its interleaved passes)
+
+#ifndef KMX_LOOKUP_OCC
+#define KMX_LOOKUP_OCC 5        // waves per SIMD k_lookup is compiled for
+#endif
+__global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxIndexDev* __restrict__ ix,
                                                       const uint8_t* __restrict__ qranks,
                                                       const uint64_t* __restrict__ qoff, uint64_t nq,
                                                       QueryDesc d, unsigned long long* __restrict__ ctr,
@@ -496,16 +583,22 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     // job, for free here)
     __shared__ BlockCounters bc;
     __shared__ KmxElemDev elems_s[KMX_MAX_KS];      // the element descriptors: read at LDS latency, no vector-memory issue
+    __shared__ uint32_t plan_s[KMX_PLAN_LDS];       // the planner's entries of the short lengths (second summand of a multi-k pair)
+    static_assert(KMX_PLAN_LDS == KMX_BLOCK, "one planner entry per thread");
     if (threadIdx.x == 0) {
-        bc.n_stitch = bc.n_stitch_tiny = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_prefix_merge = bc.n_prefix_mid = bc.n_prefix_plain = bc.n_error = bc.n_none = bc.n_more = 0;
+        bc.n_stitch = bc.n_stitch_tiny = bc.n_stitch_short = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_prefix_merge = bc.n_prefix_mid = bc.n_prefix_plain = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = bc.hits = 0;
         bc.max_runs = 0;
+        unsigned int j = 0;
+        while (j < 63 && ix->pw[j + 1] <= KMX_SUBK_FANOUT_LIMIT) ++j;
+        bc.max_fan_exp = j;
     }
     {
         const uint32_t n_words = ix->n_ks * uint32_t(sizeof(KmxElemDev) / 8);
         const uint64_t* __restrict__ srcw = reinterpret_cast<const uint64_t*>(ix->elems);
         uint64_t* dstw = reinterpret_cast<uint64_t*>(elems_s);
         for (uint32_t i = threadIdx.x; i < n_words; i += KMX_BLOCK) dstw[i] = srcw[i];
+        plan_s[threadIdx.x] = threadIdx.x < ix->range ? ((const KMX_GLOBAL uint32_t*)ix->plan)[threadIdx.x] : 0u;
     }
     const uint8_t* __restrict__ qend = qranks + qoff[nq];
     __syncthreads();
@@ -517,185 +610,52 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
     unsigned long long locw[KMX_LOOKUP_ITEMS];
     bool done[KMX_LOOKUP_ITEMS];
     uint64_t my_hits = 0;
+    const uint32_t sigma = ix->sigma, range = ix->range;
+    const uint8_t* __restrict__ dummy = reinterpret_cast<const uint8_t*>(ix);     // always >= 64 readable bytes
 
-    // ---- pass 1: the plain exact lookup (m == k <= 16, :198-205), the thread's queries INTERLEAVED:
-    // all offsets, then all plan entries, then all letter loads, then all probes — one memory round
-    // trip per phase instead of one per query and phase.
-    {
-        const uint32_t sigma = ix->sigma, range = ix->range;
-        const uint8_t* __restrict__ dummy = reinterpret_cast<const uint8_t*>(ix);     // always >= 16 readable bytes
-        uint64_t qb[KMX_LOOKUP_ITEMS];
-        uint32_t qm[KMX_LOOKUP_ITEMS];
-        uint32_t praw[KMX_LOOKUP_ITEMS];
-        u32x4_a1 w[KMX_LOOKUP_ITEMS];
-        uint64_t hs[KMX_LOOKUP_ITEMS];
-        bool rok[KMX_LOOKUP_ITEMS];
-        u32x4_a1 pr[KMX_LOOKUP_ITEMS];
-        unsigned int n_none = 0, n_err = 0;
-#pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
-            const uint64_t qq = q < nq ? q : nq - 1;
-            qb[it] = qoff[qq];
-            const uint64_t mlen = qoff[qq + 1] - qb[it];
-            qm[it] = mlen > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(mlen);
-        }
-#pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it)
-            praw[it] = ((const KMX_GLOBAL uint32_t*)ix->plan)[min(qm[it], range - 1)];
-#pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
-            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
-            done[it] = q < nq && qm[it] > 0 && qm[it] < range && (praw[it] & 0xFF) == KMX_SCHEME_SINGLE && el->k == qm[it] &&
-                       qm[it] <= 16 && qranks + qb[it] + 16 <= qend;
-            w[it] = *reinterpret_cast<const u32x4_a1*>(done[it] ? qranks + qb[it] : dummy);
-        }
-#pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
-            uint64_t lo = uint64_t(w[it][0]) | (uint64_t(w[it][1]) << 32), hi = uint64_t(w[it][2]) | (uint64_t(w[it][3]) << 32);
-            uint64_t acc = 0;
-            bool ok = true;
-            const uint32_t len = done[it] ? qm[it] : 0u;
-            for (uint32_t j = 0; j < len; ++j) {
-                const uint32_t r = uint32_t(lo & 0xFF);
-                lo = (lo >> 8) | (hi << 56);
-                hi >>= 8;
-                ok &= r < sigma;
-                acc = acc * sigma + r;
-            }
-            hs[it] = acc;
-            rok[it] = ok;
-            // first probe: dense -> offs[h], offs[h+1]; open -> the slot {key, off, cnt}; both as one 16-byte load
-            const char* addr = reinterpret_cast<const char*>(dummy);
-            if (done[it] && ok) {
-                if (el->table_kind == KMX_TABLE_DENSE) {
-                    addr = el->cnt8 ? reinterpret_cast<const char*>(el->cnt8 + (acc & ~uint64_t(15)))    // the aligned 16 bytes holding cnt8[h]
-                                    : reinterpret_cast<const char*>((el->atab ? el->atab : el->offs) + acc);
-                } else {
-                    addr = reinterpret_cast<const char*>(el->slots + slot_hash_dev(acc, el->log2cap));
-                }
-            }
-            pr[it] = *(const KMX_GLOBAL u32x4_a1*)addr;
-        }
-#pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-            kinds[it] = KMX_KIND_NONE;
-            locs[it] = 0;
-            locw[it] = 0;
-            if (!done[it]) continue;
-            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
-            const KmxElemDev* el = &elems_s[(praw[it] >> 8) & 0xFF];
-            uint64_t src = 0;
-            uint32_t cnt = 0;
-            uint8_t status = KMX_Q_OK;
-            if (!rok[it]) {
-                status = KMX_Q_BAD_RANK;
-            } else if (el->table_kind == KMX_TABLE_DENSE) {
-                if (el->cnt8) {
-                    const uint32_t b = uint32_t(hs[it]) & 15u;
-                    const uint32_t wsel = (b >> 2) == 0 ? pr[it][0] : (b >> 2) == 1 ? pr[it][1] : (b >> 2) == 2 ? pr[it][2] : pr[it][3];
-                    const uint32_t c = (wsel >> ((b & 3u) * 8u)) & 0xFFu;
-                    if (c != 255u) { src = el->cell_base + (hs[it] << el->cell_shift); cnt = c; }
-                    else {                                    // (rare) the group is longer than a cell: the contiguous copy
-                        const KMX_GLOBAL uint32_t* offs = as_global(el->offs);
-                        const uint32_t a = offs[hs[it]], b = offs[hs[it] + 1];
-                        src = el->arena_base + a; cnt = b - a;
-                    }
-                }
-                else if (el->atab) { src = el->arena_base + (pr[it][0] & ~31u); cnt = atab_count(pr[it][0], pr[it][1]); }
-                else { src = el->arena_base + pr[it][0]; cnt = pr[it][1] - pr[it][0]; }
-            } else {
-                // linear probing continues from the prefetched slot (at(hash), :76-84)
-                const KMX_GLOBAL KmxSlot* slots = as_global(el->slots);
-                const uint64_t mask = (uint64_t(1) << el->log2cap) - 1;
-                uint64_t s = slot_hash_dev(hs[it], el->log2cap);
-                uint64_t key = uint64_t(pr[it][0]) | (uint64_t(pr[it][1]) << 32);
-                uint32_t off = pr[it][2], c = pr[it][3];
-                while (c != 0 && key != hs[it]) {
-                    s = (s + 1) & mask;
-                    const u64x2 raw = *(const KMX_GLOBAL u64x2*)(slots + s);
-                    key = raw.x; off = uint32_t(raw.y); c = uint32_t(raw.y >> 32);
-                }
-                if (c) { src = el->arena_base + off; cnt = c; }
-            }
-            const uint8_t kind = cnt ? KMX_KIND_EXACT : KMX_KIND_NONE;
-            n_err += status != KMX_Q_OK;
-            n_none += status == KMX_Q_OK && !cnt;
-            d.src[q] = src;
-            d.cnt[q] = cnt;
-            d.kind[q] = kind;
-            d.status[q] = status;
-            my_hits += cnt;
-        }
-        if (n_err) atomicAdd(&bc.n_error, n_err);
-        if (n_none) atomicAdd(&bc.n_none, n_none);
-    }
-
-    // ---- pass 2: everything else (other lengths, multi-k schemes, long queries), one query at a time
-#pragma unroll 1
-    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-    if (done[it]) continue;
-    const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
-    uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
-    uint64_t src = 0, aux = 0, key = 0;
-    uint64_t p1 = 0;              // STITCH: one further part as (offset in query << 32) | bucket size, bucket in `key`; bit 63: more parts follow
-    uint32_t cnt = 0, c0 = 0;
-    unsigned int my_stitch = 0, my_prefix = 0;
-    unsigned long long my_words = 0;
-    bool resolved = false;        // a STITCH query whose few candidates were followed through every part right here
-
-    if (q < nq) {
-        const uint64_t b = qoff[q];
-        const uint64_t m = qoff[q + 1] - b;
-        const uint8_t* __restrict__ qr = qranks + b;
-        LookupOut lo;
-        lookup_query(ix, elems_s, qr, m, qend, flags, lo);
-        kind = lo.kind; status = lo.status; src = lo.src; aux = lo.aux; key = lo.key; p1 = lo.p1; cnt = lo.cnt; c0 = lo.c0; resolved = lo.resolved;
-        my_prefix = kind == KMX_KIND_PREFIX;
+    // One query's descriptor out, with the block-aggregated bookkeeping of the work lists (LDS counters now, one global atomic
+    // per counter and block later).  Everything that is not a plain exact lookup ends here: STITCH queries are sorted into the
+    // tiny / short / general classes of the validation kernels, PREFIX ones into the classes of the merge kernels.
+    auto emit = [&](int it, uint64_t q, uint8_t kind, uint8_t status, uint64_t src, uint64_t aux, uint64_t key, uint64_t p1, uint32_t cnt,
+                    uint32_t c0, bool resolved) {
+        unsigned int loc = 0;
+        unsigned long long loc_words = 0;
         if (kind == KMX_KIND_STITCH && !resolved) {
-            my_stitch = 1;
-            my_words = uint64_t(c0) / 64 + 1;                 // compressed_bitset.hpp:23
+            const uint32_t pc = uint32_t(p1);
+            if (min(c0, pc) <= KMX_VTINY && max(c0, pc) <= 2 * KMX_VTINY) {
+                loc = atomicAdd(&bc.n_stitch_tiny, 1u) | 0x80000000u;    // tiny: one thread validates it, listed from the back
+            } else if (!(p1 & (KMX_P1_MORE | KMX_P1_BIG)) && min(c0, pc) <= KMX_VSHORT && max(c0, pc) <= KMX_VSTAGE) {
+                loc = atomicAdd(&bc.n_stitch_short, 1u) | 0x40000000u;   // short: a list of its own; the shorter bucket is the one walked
+                if (pc < c0) p1 |= KMX_P1_SWAP;
+            } else {
+                if ((p1 & (KMX_P1_MORE | KMX_P1_BIG)) || stitch_is_wide(p1)) atomicAdd(&bc.n_more, 1u);
+                loc = atomicAdd(&bc.n_stitch, 1u);
+            }
+            loc_words = atomicAdd(&bc.words, (unsigned long long)(uint64_t(c0) / 64 + 1));      // compressed_bitset.hpp:23
         }
-    }
-
-    // block-aggregated bookkeeping: LDS counters now, one global atomic per counter per block later
-    unsigned int loc = 0;
-    unsigned long long loc_words = 0;
-    if (my_stitch) {
-        if (c0 <= KMX_VTINY && uint32_t(p1) <= KMX_VTINY) {
-            loc = atomicAdd(&bc.n_stitch_tiny, 1u) | 0x80000000u;    // tiny: one thread validates it, listed from the back
-        } else {
-            if ((p1 & (KMX_P1_MORE | KMX_P1_BIG)) || stitch_is_wide(p1)) atomicAdd(&bc.n_more, 1u);
-            loc = atomicAdd(&bc.n_stitch, 1u);
-        }
-        loc_words = atomicAdd(&bc.words, my_words);
-    }
-    if (my_prefix) {
-        const uint32_t plen = cnt - uint32_t(__popcll(aux));
-        if (c0 < 2 || plen < 2) {
-            loc = 0xFFFFFFFFu;                                   // one list (a prefix level's, or the only key): in order as it lies, not listed
-            atomicAdd(&bc.n_prefix_plain, 1u);
-        } else if (KMX_PSORT_IS_SMALL(c0, plen)) {
-            loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
-            if (KMX_PSORT_IS_MERGE(c0, plen)) atomicAdd(&bc.n_prefix_merge, 1u);
-        } else {
-            loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
-            if (plen <= KMX_PSORT_MID_CAP) atomicAdd(&bc.n_prefix_mid, 1u);
-            if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: chunks sorted in LDS, then merged in global memory
-                atomicAdd(&bc.pelems, (unsigned long long)plen);
-                atomicMax(&bc.max_runs, (plen + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP);
+        if (kind == KMX_KIND_PREFIX) {
+            const uint32_t plen = cnt - uint32_t(__popcll(aux));
+            if (c0 < 2 || plen < 2) {
+                loc = 0xFFFFFFFFu;                                   // one list (a prefix level's, or the only key): in order as it lies, not listed
+                atomicAdd(&bc.n_prefix_plain, 1u);
+            } else if (KMX_PSORT_IS_SMALL(c0, plen)) {
+                loc = atomicAdd(&bc.n_prefix, 1u);                   // small: listed from the front
+                if (KMX_PSORT_IS_MERGE(c0, plen)) atomicAdd(&bc.n_prefix_merge, 1u);
+            } else {
+                loc = atomicAdd(&bc.n_prefix_big, 1u) | 0x80000000u; // mid / large: listed from the back
+                if (plen <= KMX_PSORT_MID_CAP) atomicAdd(&bc.n_prefix_mid, 1u);
+                if (plen > KMX_PSORT_BLOCK_CAP) {                    // large: chunks sorted in LDS, then merged in global memory
+                    atomicAdd(&bc.pelems, (unsigned long long)plen);
+                    atomicMax(&bc.max_runs, (plen + KMX_PSORT_BLOCK_CAP - 1) / KMX_PSORT_BLOCK_CAP);
+                }
             }
         }
-    }
-    if (resolved) atomicAdd(&bc.n_resolved, 1u);
-    if (q < nq && status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
-    if (q < nq && status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
-    kinds[it] = (q < nq && !resolved) ? kind : uint8_t(KMX_KIND_NONE);    // (only the work-list bookkeeping below reads this)
-    locs[it] = loc;
-    locw[it] = loc_words;
-    if (q < nq) {
+        if (resolved) atomicAdd(&bc.n_resolved, 1u);
+        if (status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
+        if (status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
+        kinds[it] = !resolved ? kind : uint8_t(KMX_KIND_NONE);    // (only the work-list bookkeeping at the end reads this)
+        locs[it] = loc;
+        locw[it] = loc_words;
         my_hits += cnt;
         d.src[q] = (kind == KMX_KIND_STITCH && !resolved) ? (src | SRC_SLOW) : (kind == KMX_KIND_PREFIX ? (src | SRC_FLAGS) : src);
         d.cnt[q] = cnt;
@@ -710,17 +670,200 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
             d.aux[q] = aux;
             d.key[q] = key;
         }
+    };
+
+    uint64_t qb[KMX_LOOKUP_ITEMS];
+    uint32_t qm[KMX_LOOKUP_ITEMS];
+    uint32_t praw[KMX_LOOKUP_ITEMS];
+#pragma unroll
+    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+        const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+        const uint64_t qq = q < nq ? q : nq - 1;
+        qb[it] = qoff[qq];
+        const uint64_t mlen = qoff[qq + 1] - qb[it];
+        qm[it] = mlen > 0xFFFFFFFFull ? 0xFFFFFFFFu : uint32_t(mlen);
+        kinds[it] = KMX_KIND_NONE;
+        locs[it] = 0;
+        locw[it] = 0;
     }
-    }   // items
+#pragma unroll
+    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it)
+        praw[it] = plan_effective(((const KMX_GLOBAL uint32_t*)ix->plan)[min(qm[it], range - 1)]);
+
+    // ---- pass 1: the plain exact lookup (m == k <= 16, :198-205) and cross-referenced queries of exactly TWO parts with
+    // k <= 16 each — one k with k < m <= 2k (:207-298: the second part is the k-mer that ends the query), or a multi-k pair
+    // (:515-555) — with the thread's queries INTERLEAVED: all offsets, then all plan entries, then all letter loads (both parts),
+    // then all probes (both parts) — one memory round trip per phase instead of one per query, part and phase.
+    {
+        uint32_t eab[KMX_LOOKUP_ITEMS];                    // element of the first part | element of the second << 8 | offset of the second << 16
+        bool two[KMX_LOOKUP_ITEMS];
+        u32x4_a1 wa[KMX_LOOKUP_ITEMS], wb[KMX_LOOKUP_ITEMS];
+        unsigned int n_none = 0, n_err = 0;
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            const uint32_t m = qm[it], scheme = praw[it] & 0xFF, e = (praw[it] >> 8) & 0xFF;
+            const uint32_t kb = elems_s[e].k;
+            const bool live = q < nq && m > 0 && m < range;
+            const bool one = live && scheme == KMX_SCHEME_SINGLE && kb == m && m <= 16 && qranks + qb[it] + 16 <= qend;
+            bool t = false;
+            uint32_t ea = e, off = 0;
+            if (live && !one && m < KMX_PLAN_LDS) {
+                if (scheme == KMX_SCHEME_SINGLE) {
+                    const uint32_t rest = m < 2 * kb ? m - kb : 0u;                   // (m > kb checked below)
+                    t = m > kb && m <= 2 * kb && kb <= 16 && (rest == 0 || kb - rest <= bc.max_fan_exp);   // (:119-122 via :234 stays with pass 2)
+                    off = m - kb;
+                } else if (scheme == KMX_SCHEME_MULTI && ((praw[it] >> 16) & KMX_PLAN_NPARTS_MASK) == 2 && m > kb) {
+                    // _optimal_nk_sum[m] = _optimal_nk_sum[m - k_last] + [k_last] (:434-435): the first summand is plan[m - k_last]
+                    const uint32_t p2 = plan_s[m - kb];
+                    ea = (p2 >> 8) & 0xFF;
+                    const uint32_t ka = elems_s[ea].k;
+                    t = (p2 & 0xFF) != KMX_SCHEME_NONE && ka + kb == m && ka <= 16 && kb <= 16;
+                    off = m - kb;
+                }
+                t = t && qranks + qb[it] + off + 16 <= qend;                          // (both 16-byte loads inside the letters)
+            }
+            done[it] = one || t;
+            two[it] = t;
+            eab[it] = ea | (e << 8) | (off << 16);
+            wa[it] = *reinterpret_cast<const u32x4_a1*>(done[it] ? qranks + qb[it] : dummy);
+            wb[it] = *reinterpret_cast<const u32x4_a1*>(t ? qranks + qb[it] + off : dummy);
+        }
+        uint64_t ha[KMX_LOOKUP_ITEMS], hb[KMX_LOOKUP_ITEMS];
+        bool oka[KMX_LOOKUP_ITEMS], okb[KMX_LOOKUP_ITEMS];
+        u32x4_a1 pa[KMX_LOOKUP_ITEMS], pb[KMX_LOOKUP_ITEMS];
+#pragma unroll
+        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+            const KmxElemDev* ela = &elems_s[eab[it] & 0xFF];
+            const KmxElemDev* elb = &elems_s[(eab[it] >> 8) & 0xFF];
+            oka[it] = hash16(wa[it], done[it] ? ela->k : 0u, sigma, ha[it]);
+            okb[it] = hash16(wb[it], two[it] ? elb->k : 0u, sigma, hb[it]);
+            // first probe: dense -> the table entries of h; open -> the slot {key, off, cnt}; both as one 16-byte load
+            pa[it] = *(const KMX_GLOBAL u32x4_a1*)((done[it] && oka[it]) ? probe_first_addr(ela, ha[it]) : reinterpret_cast<const char*>(dummy));
+            pb[it] = *(const KMX_GLOBAL u32x4_a1*)((two[it] && okb[it]) ? probe_first_addr(elb, hb[it]) : reinterpret_cast<const char*>(dummy));
+        }
+        // The buckets are known.  An exact lookup leaves right away; a pair whose two buckets hold at most KMX_VTINY positions
+        // each (large k: 24-letter reads as two 12-mers) is finished HERE: both buckets are read (2 x 32 bytes each, straight-line
+        // — any element of the arena may be read 32 bytes wide, its allocation is padded) and when the surviving start positions
+        // are one run of the first bucket the query leaves as a plain copy of that run — no descriptor round trip through a
+        // validation kernel, no mask words (not with KEEP_MASKS: the words are the point there).  Two queries' bucket loads are
+        // in flight at a time.
+        struct Pend {
+            bool two, tiny;
+            uint8_t kind, status;
+            uint64_t src, key, p1;
+            uint32_t c0, off, pc;
+            u32x4 a0, a1, b0, b1;
+        };
+        const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
+        auto stage1 = [&](int it) -> Pend {
+            Pend P;
+            P.two = false; P.tiny = false; P.kind = KMX_KIND_NONE; P.status = KMX_Q_OK; P.src = P.key = P.p1 = 0; P.c0 = P.off = P.pc = 0;
+            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            Run ra{0, 0}, rb{0, 0};
+            if (done[it]) {
+                const KmxElemDev* ela = &elems_s[eab[it] & 0xFF];
+                if (oka[it]) ra = probe_finish(ela, ha[it], pa[it]);
+                if (!two[it]) {
+                    const uint8_t status = oka[it] ? KMX_Q_OK : KMX_Q_BAD_RANK;
+                    n_err += status != KMX_Q_OK;
+                    n_none += status == KMX_Q_OK && !ra.cnt;
+                    d.src[q] = ra.src;
+                    d.cnt[q] = ra.cnt;
+                    d.kind[q] = ra.cnt ? KMX_KIND_EXACT : KMX_KIND_NONE;
+                    d.status[q] = status;
+                    my_hits += ra.cnt;
+                } else {
+                    const KmxElemDev* elb = &elems_s[(eab[it] >> 8) & 0xFF];
+                    const uint32_t off = eab[it] >> 16;
+                    const bool multi = (praw[it] & 0xFF) == KMX_SCHEME_MULTI;
+                    if (okb[it]) rb = probe_finish(elb, hb[it], pb[it]);
+                    // the parts are looked at in the reference's order and a miss ends the walk (:216-227; :519-527 from the last
+                    // summand): a letter outside the alphabet only counts in a part the walk reaches
+                    const bool bad = multi ? (!okb[it] || (rb.cnt != 0 && !oka[it])) : (!oka[it] || (ra.cnt != 0 && !okb[it]));
+                    P.two = true;
+                    if (bad) {
+                        P.status = KMX_Q_BAD_RANK;
+                    } else if (ra.cnt != 0 && rb.cnt != 0) {
+                        P.kind = KMX_KIND_STITCH; P.src = ra.src; P.c0 = ra.cnt; P.key = rb.src; P.off = off; P.pc = rb.cnt;
+                        P.p1 = (uint64_t(off) << 32) | rb.cnt;
+                        if (!(flags & KMX_SEARCH_KEEP_MASKS) && stitch_goes_big(ra.cnt, rb.cnt)) P.p1 |= KMX_P1_BIG;
+                        P.tiny = !(flags & KMX_SEARCH_KEEP_MASKS) && ra.cnt <= KMX_VTINY && rb.cnt <= KMX_VTINY;
+                    }
+                }
+            }
+            static_assert(KMX_VTINY == 8, "two 16-byte loads per bucket");
+            const uint64_t sa = P.tiny ? ra.src : 0, sb = P.tiny ? rb.src : 0;
+            P.a0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sa); P.a1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sa + 4);
+            P.b0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sb); P.b1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sb + 4);
+            return P;
+        };
+        auto stage2 = [&](int it, const Pend& P) {
+            if (!P.two) return;
+            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            uint64_t src = P.src;
+            uint32_t cnt = 0;
+            bool resolved = false;
+            if (P.tiny) {
+                const uint32_t av[8] = {P.a0.x, P.a0.y, P.a0.z, P.a0.w, P.a1.x, P.a1.y, P.a1.z, P.a1.w};
+                const uint32_t bv[8] = {P.b0.x, P.b0.y, P.b0.z, P.b0.w, P.b1.x, P.b1.y, P.b1.z, P.b1.w};
+                uint32_t alive = 0;
+#pragma unroll
+                for (uint32_t i = 0; i < 8; ++i) {
+                    bool hit = false;
+#pragma unroll
+                    for (uint32_t j = 0; j < 8; ++j) hit |= j < P.pc && av[i] + P.off == bv[j];      // binary_search :283, lower_bound :544-546
+                    alive |= uint32_t(hit && i < P.c0) << i;
+                }
+                const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
+                if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
+                    resolved = true;
+                    src = P.src + lo;
+                    cnt = len;
+                }
+            }
+            emit(it, q, P.kind, P.status, src, 0, P.key, P.p1, cnt, P.c0, resolved);
+        };
+        static_assert(KMX_LOOKUP_ITEMS == 4 || KMX_LOOKUP_ITEMS == 8, "the two-in-flight schedule below");
+        {
+            Pend p0 = stage1(0);
+            Pend p1 = stage1(1);
+#pragma unroll
+            for (int it = 2; it < KMX_LOOKUP_ITEMS; it += 2) {
+                stage2(it - 2, p0);
+                p0 = stage1(it);
+                stage2(it - 1, p1);
+                p1 = stage1(it + 1);
+            }
+            stage2(KMX_LOOKUP_ITEMS - 2, p0);
+            stage2(KMX_LOOKUP_ITEMS - 1, p1);
+        }
+        if (n_err) atomicAdd(&bc.n_error, n_err);
+        if (n_none) atomicAdd(&bc.n_none, n_none);
+    }
+
+    // ---- pass 2: everything else (other lengths, long queries, more parts), one query at a time
+#pragma unroll 1
+    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+        if (done[it]) continue;
+        const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+        if (q >= nq) continue;
+        const uint64_t b = qoff[q];
+        const uint64_t m = qoff[q + 1] - b;
+        LookupOut lo;
+        lookup_query(ix, elems_s, qranks + b, m, qend, flags, lo);
+        emit(it, q, lo.kind, lo.status, lo.src, lo.aux, lo.key, lo.p1, lo.cnt, lo.c0, lo.resolved);
+    }
 
     for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_xor(my_hits, off);
     if (lane_id() == 0 && my_hits) atomicAdd(&bc.hits, (unsigned long long)my_hits);
     __syncthreads();
     if (threadIdx.x == 0) {
         if (block_hits) block_hits[blockIdx.x] = bc.hits;
-        if (bc.n_stitch | bc.n_stitch_tiny) {
+        if (bc.n_stitch | bc.n_stitch_tiny | bc.n_stitch_short) {
             if (bc.n_stitch) bc.base_stitch = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH], (unsigned long long)bc.n_stitch);
             if (bc.n_stitch_tiny) bc.base_stitch_tiny = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH_TINY], (unsigned long long)bc.n_stitch_tiny);
+            if (bc.n_stitch_short) bc.base_stitch_short = (unsigned int)atomicAdd(&ctr[KMX_CTR_STITCH_SHORT], (unsigned long long)bc.n_stitch_short);
             bc.base_words = atomicAdd(&ctr[KMX_CTR_MASK_WORDS], bc.words);
             if (bc.n_more) atomicAdd(&ctr[KMX_CTR_STITCH_MORE], (unsigned long long)bc.n_more);
         }
@@ -743,7 +886,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
         const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
         if (kinds[it] == KMX_KIND_STITCH) {
             d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
-            if (locs[it] & 0x80000000u) d.stitch_list[nq - 1 - (bc.base_stitch_tiny + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
+            if (locs[it] & 0x80000000u) d.stitch_list[nq - 1 - (bc.base_stitch_tiny + (locs[it] & 0x3FFFFFFFu))] = uint32_t(q);
+            else if (locs[it] & 0x40000000u) d.short_list[bc.base_stitch_short + (locs[it] & 0x3FFFFFFFu)] = uint32_t(q);
             else d.stitch_list[bc.base_stitch + locs[it]] = uint32_t(q);
         } else if (kinds[it] == KMX_KIND_PREFIX && locs[it] != 0xFFFFFFFFu) {
             if (locs[it] & 0x80000000u) d.prefix_list[nq - 1 - (bc.base_prefix_big + (locs[it] & 0x7FFFFFFFu))] = uint32_t(q);
@@ -768,11 +912,6 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_lookup(const KmxIndexDev* __restr
 // by chance with probability bucket/n — one part per lane of the group.  64 candidates = one
 // compressed_bitset word, assembled from 16-bit slices of the wave's ballots.
 // ---------------------------------------------------------------------------
-#define KMX_VGROUP 16                            // 32 and 64 lanes per query measured slower
-#define KMX_VGROUPS (KMX_WAVE / KMX_VGROUP)
-#define KMX_VSLICES (64 / KMX_VGROUP)            // ballot slices per mask word
-#define KMX_VSTAGE (1024 / KMX_VGROUPS)          // staged bucket entries per group (4 KB of LDS per wave)
-#define KMX_VCH 8                                // rounds of KMX_VGROUP candidates searched in lockstep
 // Does candidate position p continue with every further part of query q?  Called by a whole KMX_VGROUP-lane
 // group (gl = lane in group); lane gl takes parts gl, gl + 16, ...  Part e of a single-k query: the k-part at
 // (e + 1) * k (:279-291), last the k-mer that ends the query when there is a rest; of a multi-k query: the
@@ -812,7 +951,7 @@ __device__ __forceinline__ bool stitch_parts_hold(const KmxIndexDev* __restrict_
             const KmxElemDev* __restrict__ el = nullptr;
             uint32_t k = 0;
             for (; walked <= e; ++walked) {
-                const KmxPlanEntry en = load_plan(ix, mm);
+                const KmxPlanEntry en = load_plan_chain(ix, mm);
                 el = &ix->elems[en.elem];
                 k = el->k;
                 mm -= k;                                               // this summand covers [mm, mm + k)
@@ -855,6 +994,11 @@ __device__ __forceinline__ uint32_t staged_members(const uint32_t* __restrict__ 
 
 // INLINE_MORE: the survivors' further parts are checked right here (more registers, and the groups of a wave wait
 // for each other's survivors); otherwise k_validate_more does it afterwards from the survivor lists.
+//
+// A chunk = 128 candidates of every group's query: lane gl of the group takes the EIGHT CONSECUTIVE candidates
+// [128 c + 8 gl, 128 c + 8 gl + 8) — two 16-byte loads — and searches them in lockstep; its eight verdicts are byte gl of the
+// chunk's 128 mask bits (compressed_bitset.hpp:13-14: bit i = word i >> 6, bit i & 63), so the two mask words of a chunk are
+// assembled by sixteen one-byte LDS stores and read back with one 16-byte LDS load — no ballots, no per-round bookkeeping.
 template <bool INLINE_MORE>
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
                                                         const uint32_t* __restrict__ arena,
@@ -863,24 +1007,46 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                                                         uint64_t n_stitch, uint64_t* __restrict__ mask_words)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VSTAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t verdicts[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VGROUP];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x / KMX_WAVE;
     const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
-    static_assert(KMX_VGROUP == 16 && KMX_VGROUPS == 4, "the mask word assembly below is written for four 16-lane groups");
+    static_assert(KMX_VGROUP == 16 && KMX_VGROUPS == 4 && KMX_VCH == 8, "a chunk is 16 lanes x 8 candidates = two mask words");
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    // the bits of the chunk's four 32-bit quarters that lie below this lane's byte (8 gl): ranks of the survivors
+    uint32_t below[4];
+#pragma unroll
+    for (uint32_t w = 0; w < 4; ++w) below[w] = 8 * gl >= 32 * (w + 1) ? 0xFFFFFFFFu : 8 * gl <= 32 * w ? 0u : (1u << (8 * gl - 32 * w)) - 1u;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
 
-    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
+    // The chain list entry -> descriptor -> buckets is three dependent memory round trips per query; a wave that walked it
+    // once per round would spend its time waiting.  So the loop is software-pipelined: the descriptor of the NEXT round's
+    // query and the list entry of the round after it are loaded while this round's candidates are searched.
+    // (straight-line loads: an index past the end of the list reads the list's last query and is masked by `have`)
+    const uint64_t stride = n_waves * KMX_VGROUPS;
+    auto list_at = [&](uint64_t i) -> uint32_t { return d.stitch_list[min(i, n_stitch - 1)]; };
+    uint32_t q_next = list_at(wave * KMX_VGROUPS + g);
+    uint32_t q_after = list_at(wave * KMX_VGROUPS + stride + g);
+    uint32_t n_c0 = d.c0[q_next];
+    uint64_t n_src = d.src[q_next], n_p1 = d.p1[q_next], n_key = d.key[q_next], n_aux = d.aux[q_next];
+    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += stride) {
         const uint64_t i = i0 + g;
         const bool have = i < n_stitch;
-        // straight-line loads: a group past the end of the list reads the list's last query and is masked by `have`
-        const uint32_t q = d.stitch_list[min(i, n_stitch - 1)];
-        // one round of independent loads per group
-        const uint32_t c0 = d.c0[q];
-        const uint64_t src_raw = d.src[q];
-        const uint64_t p1 = d.p1[q];
-        const uint64_t p1src = d.key[q];
-        const uint64_t wbase = d.aux[q];
+        const uint32_t q = q_next;
+        const uint32_t c0 = n_c0;
+        const uint64_t src_raw = n_src;
+        const uint64_t p1 = n_p1;
+        const uint64_t p1src = n_key;
+        const uint64_t wbase = n_aux;
+        // the next round's descriptor (its query came with the previous round), and the list entry of the round behind it
+        q_next = q_after;
+        n_c0 = d.c0[q_next]; n_src = d.src[q_next]; n_p1 = d.p1[q_next]; n_key = d.key[q_next]; n_aux = d.aux[q_next];
+        q_after = list_at(i + 2 * stride);
         const uint64_t src = src_raw & ~SRC_FLAGS;
         uint64_t* __restrict__ words = mask_words + wbase;
         const uint64_t sbase = wbase * 64;
@@ -891,16 +1057,26 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         // The staged bucket is padded with 0xFFFFFFFF (never a position) to the wave's largest power of
         // two, so that the search below is a fixed number of branch-free halving steps for all four groups.
         uint32_t P = (staged && pcnt > 1) ? (1u << (32 - __clz(int(pcnt - 1)))) : 1u;
-        uint32_t max_it = fast ? (c0 + KMX_VGROUP - 1) / KMX_VGROUP : 0u;
-        const uint32_t n_it = max_it;
-#pragma unroll
-        for (int e = 1; e < KMX_VGROUPS; ++e) {
-            P = max(P, uint32_t(__shfl_xor(int(P), e * KMX_VGROUP)));
-            max_it = max(max_it, uint32_t(__shfl_xor(int(max_it), e * KMX_VGROUP)));
+        const uint32_t n_ch = fast ? (c0 + KMX_VGROUP * KMX_VCH - 1) / (KMX_VGROUP * KMX_VCH) : 0u;     // chunks of this group's query
+        uint32_t max_ch = n_ch;
+        {
+            // (butterfly over the four groups: two exchanges)
+            P = max(P, uint32_t(__shfl_xor(int(P), KMX_VGROUP)));
+            max_ch = max(max_ch, uint32_t(__shfl_xor(int(max_ch), KMX_VGROUP)));
+            P = max(P, uint32_t(__shfl_xor(int(P), 2 * KMX_VGROUP)));
+            max_ch = max(max_ch, uint32_t(__shfl_xor(int(max_ch), 2 * KMX_VGROUP)));
         }
         P = uint32_t(__builtin_amdgcn_readfirstlane(int(P)));
-        max_it = uint32_t(__builtin_amdgcn_readfirstlane(int(max_it)));
+        max_ch = uint32_t(__builtin_amdgcn_readfirstlane(int(max_ch)));
         uint32_t* __restrict__ arr = stage[wv][g];
+        // the candidates of the first chunk are asked for BEFORE the filter bucket is staged: both buckets travel together
+        // (one pointer per lane and chunk, clamped to the bucket's last entry: a dead slot reads at most 7 entries past the
+        // bucket, inside the arena's KMX_ARENA_PAD)
+        static_assert(KMX_VCH * 4 + 16 <= KMX_ARENA_PAD, "the dead slots of a chunk must stay inside the arena's padding");
+        const uint32_t* __restrict__ cand = arena + src;
+        const uint32_t c_last = (fast && c0) ? c0 - 1u : 0u;
+        const uint32_t* __restrict__ cp = cand + min(gl * KMX_VCH, c_last);
+        u32x4 v0 = *reinterpret_cast<const u32x4_a4*>(cp), v1 = *reinterpret_cast<const u32x4_a4*>(cp + 4);
         {
             // four consecutive entries per lane and step: one 16-byte load (any element of the arena may be read 16 bytes
             // wide: its allocation is padded), one 16-byte LDS store; a lane past the bucket re-reads its last entry.
@@ -917,40 +1093,23 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                 *reinterpret_cast<u32x4*>(arr + t) = v;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        wsync();
 
         uint32_t valid = 0;
-        const uint32_t lt_mask = (1u << gl) - 1u;
-        const uint32_t* __restrict__ cand = arena + src;
-        const uint32_t c_last = (fast && c0) ? c0 - 1u : 0u;
         const bool unstaged = fast && !staged;
-        // KMX_VCH rounds of 16 candidates at a time: their loads go out together and their searches advance
-        // in lockstep, so one global and log2(P) + 1 LDS round trips are exposed per chunk instead of per round
-        for (uint32_t it0 = 0; it0 < max_it; it0 += KMX_VCH) {
-            const uint32_t nr = min(uint32_t(KMX_VCH), max_it - it0);  // wave-uniform
-            const uint32_t ci0 = it0 * KMX_VGROUP + gl;
-            uint32_t x[KMX_VCH];
-            // one pointer per lane and chunk, clamped to the bucket's last entry; the rounds are immediate offsets from it
-            // (a dead slot reads at most 7 x 16 entries past the bucket: inside the arena's KMX_ARENA_PAD)
-            static_assert((KMX_VCH - 1) * KMX_VGROUP * 4 + 16 <= KMX_ARENA_PAD, "the dead slots of a chunk must stay inside the arena's padding");
-            const uint32_t* __restrict__ cp = cand + min(ci0, c_last);
-#pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r) x[r] = cp[r * KMX_VGROUP];
-#pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r) x[r] += delta;
-            // bit r: this lane has a candidate in round r
-            const uint32_t n_live = (fast && ci0 < c0) ? min(uint32_t(KMX_VCH), (c0 - ci0 + KMX_VGROUP - 1) / KMX_VGROUP) : 0u;
-            const uint32_t livem = (1u << n_live) - 1u;
-            uint32_t okm;                                               // bit r: this lane's candidate of round r holds so far
-            switch ((nr + 1) >> 1) {                                    // (straight-line code for 2, 4, 6 or 8 rounds)
-                case 1: okm = staged_members<2>(arr, P, x); break;
-                case 2: okm = staged_members<4>(arr, P, x); break;
-                case 3: okm = staged_members<6>(arr, P, x); break;
-                default: okm = staged_members<8>(arr, P, x); break;
+        uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + sbase : nullptr;
+        for (uint32_t ch = 0; ch < max_ch; ++ch) {
+            const uint32_t ci0 = ch * (KMX_VGROUP * KMX_VCH) + gl * KMX_VCH;          // this lane's first candidate
+            const uint32_t x[KMX_VCH] = {v0.x + delta, v0.y + delta, v0.z + delta, v0.w + delta, v1.x + delta, v1.y + delta, v1.z + delta, v1.w + delta};
+            const uint32_t* __restrict__ cp_cur = cp;
+            if (ch + 1 < max_ch) {                                      // (wave-uniform) the next chunk's candidates, while this one is searched
+                cp = cand + min(ci0 + KMX_VGROUP * KMX_VCH, c_last);
+                v0 = *reinterpret_cast<const u32x4_a4*>(cp); v1 = *reinterpret_cast<const u32x4_a4*>(cp + 4);
             }
-            okm &= livem;
+            // bit r: this lane has a candidate in slot r
+            const uint32_t n_live = (fast && ci0 < c0) ? min(uint32_t(KMX_VCH), c0 - ci0) : 0u;
+            const uint32_t livem = (1u << n_live) - 1u;
+            uint32_t okm = staged_members<KMX_VCH>(arr, P, x) & livem;   // bit r: this lane's candidate r holds so far
             if (__any(unstaged)) {                                      // a filter bucket too long for LDS: searched where it lies
                 if (unstaged) {
                     okm = 0;
@@ -963,48 +1122,138 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
             if (INLINE_MORE && __any(more && okm != 0)) {
                 // queries with further parts: the survivors of the filter, one per group at a time
 #pragma unroll 1
-                for (uint32_t r = 0; r < nr; ++r) {
+                for (uint32_t r = 0; r < KMX_VCH; ++r) {
                     uint32_t pend = uint32_t(__ballot(more && ((okm >> r) & 1u)) >> (KMX_VGROUP * g)) & 0xFFFFu;   // group-uniform
                     uint32_t dropped = 0;
                     while (__any(pend != 0)) {
                         if (pend) {
                             const uint32_t bsel = uint32_t(__ffs(int(pend))) - 1u;
-                            const uint32_t pc = arena[src + uint64_t(it0 + r) * KMX_VGROUP + bsel];
+                            const uint32_t pc = arena[src + uint64_t(ch) * (KMX_VGROUP * KMX_VCH) + bsel * KMX_VCH + r];
                             const bool good = stitch_parts_hold(ix, arena, qranks, qoff, q, pc, gl);
-                            const uint32_t verdicts = uint32_t(__ballot(good) >> (KMX_VGROUP * g)) & 0xFFFFu;
-                            if (verdicts != 0xFFFFu) dropped |= 1u << bsel;
+                            const uint32_t verdicts16 = uint32_t(__ballot(good) >> (KMX_VGROUP * g)) & 0xFFFFu;
+                            if (verdicts16 != 0xFFFFu) dropped |= 1u << bsel;
                             pend &= pend - 1;
                         }
                     }
                     if ((dropped >> gl) & 1u) okm &= ~(1u << r);
                 }
             }
-            // 64 candidates = one bitset word = four rounds of 16-bit ballot slices; a chunk of KMX_VCH = 8 rounds is two
-            // words, and it0 is a multiple of 8, so which half-word a round fills is known at compile time
-            static_assert(KMX_VCH == 8, "the two-words-per-chunk assembly below");
-            uint32_t wq[4] = {0u, 0u, 0u, 0u};                          // {word A low, A high, word B low, B high}
-            uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + sbase : nullptr;
-#pragma unroll
-            for (int r = 0; r < KMX_VCH; ++r) {
-                if (uint32_t(r) >= nr) break;
-                const bool ok = (okm & (1u << r)) != 0;
-                const uint32_t s16 = uint32_t(__ballot(ok) >> (KMX_VGROUP * g)) & 0xFFFFu;
-                // survivors, already compacted and ascending: what k_fill copies out for this query
-                if (ok && sh_out) sh_out[valid + uint32_t(__popc(s16 & lt_mask))] = x[r] - delta;
-                valid += uint32_t(__popc(s16));
-                wq[r >> 1] |= s16 << ((r & 1) * 16);
+            // the chunk's 128 verdicts = two bitset words: byte gl is this lane's
+            verdicts[wv][g][gl] = uint8_t(okm);
+            wsync();
+            const u32x4 mw = *reinterpret_cast<const u32x4*>(verdicts[wv][g]);
+            if (gl == 0) {
+                if (ch < n_ch) {
+                    words[2 * ch] = (uint64_t(mw.y) << 32) | mw.x;
+                    if (ch * 128u + 64u < c0) words[2 * ch + 1] = (uint64_t(mw.w) << 32) | mw.z;
+                }
             }
-            if (gl == 0) {                                              // bit i = word i>>6, bit i&63
-                if (it0 < n_it) words[it0 >> 2] = (uint64_t(wq[1]) << 32) | wq[0];
-                if (it0 + 4 < n_it) words[(it0 >> 2) + 1] = (uint64_t(wq[3]) << 32) | wq[2];
+            if (okm && sh_out) {
+                // survivors, compacted and ascending (candidate order = lane order here): what k_fill copies out for this query
+                uint32_t at = valid + uint32_t(__popc(mw.x & below[0])) + uint32_t(__popc(mw.y & below[1])) + uint32_t(__popc(mw.z & below[2])) +
+                              uint32_t(__popc(mw.w & below[3]));
+                for (uint32_t left = okm; left; left &= left - 1)                 // (one survivor as a rule: its value is re-read, not selected)
+                    sh_out[at++] = cp_cur[uint32_t(__ffs(int(left))) - 1u];
             }
+            valid += uint32_t(__popc(mw.x)) + uint32_t(__popc(mw.y)) + uint32_t(__popc(mw.z)) + uint32_t(__popc(mw.w));
         }
         if (fast && gl == 0) {
             if ((c0 & 63) == 0) words[c0 / 64] = 0;                     // n_bits/64 + 1 words (compressed_bitset.hpp:23)
             d.cnt[q] = valid;
         }
-        __builtin_amdgcn_wave_barrier();                                // stage[] is reused by the next round
+        wsync();                                                        // stage[] is reused by the next round
+    }
+}
 
+// k_validate_short — STITCH queries of exactly TWO parts whose SHORTER bucket has at most KMX_VSHORT entries and whose longer
+// one fits a group's stage (a 10-mer + 12-mer pair on a 1e8-letter text: 95 positions against 6).  Membership is symmetric:
+// start position p survives when p is in the first part's bucket and p + offset in the second's (:279-291, :541-551) — so the
+// SHORTER list is the one walked (one entry per lane of the 16-lane group, ONE lockstep search) and the longer one staged,
+// whichever of the two is the first part (KMX_P1_SWAP: the walked entries are the second part's, the mask bit of a survivor
+// is its index in the first part's bucket, which the search has just found).  Four queries per wave.
+__global__ __launch_bounds__(KMX_BLOCK) void k_validate_short(const uint32_t* __restrict__ arena, QueryDesc d, uint64_t n_short,
+                                                              uint64_t* __restrict__ mask_words)
+{
+    constexpr uint32_t MW = KMX_VSTAGE / 64 + 1;                        // mask words of a staged first bucket
+    __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VSTAGE];
+    __shared__ unsigned long long swords[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][MW + 3];
+    const uint32_t lane = lane_id();
+    const uint32_t wv = threadIdx.x / KMX_WAVE;
+    const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    const uint32_t lt_mask = (1u << gl) - 1u;
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // (software-pipelined like k_validate: the next round's descriptor and the list entry behind it load during this round)
+    const uint64_t stride = n_waves * KMX_VGROUPS;
+    auto list_at = [&](uint64_t i) -> uint32_t { return d.short_list[min(i, n_short - 1)]; };
+    uint32_t q_next = list_at(wave * KMX_VGROUPS + g);
+    uint32_t q_after = list_at(wave * KMX_VGROUPS + stride + g);
+    uint32_t n_c0 = d.c0[q_next];
+    uint64_t n_src = d.src[q_next], n_p1 = d.p1[q_next], n_key = d.key[q_next], n_aux = d.aux[q_next];
+    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_short; i0 += stride) {
+        const uint64_t i = i0 + g;
+        const bool have = i < n_short;
+        const uint32_t q = q_next;
+        const uint32_t c0 = n_c0;
+        const uint64_t src = n_src & ~SRC_FLAGS;
+        const uint64_t p1 = n_p1;
+        const uint64_t p1src = n_key;
+        const uint64_t wbase = n_aux;
+        q_next = q_after;
+        n_c0 = d.c0[q_next]; n_src = d.src[q_next]; n_p1 = d.p1[q_next]; n_key = d.key[q_next]; n_aux = d.aux[q_next];
+        q_after = list_at(i + 2 * stride);
+        const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
+        const bool swap = (p1 & KMX_P1_SWAP) != 0;
+        // walked: n_w <= 16 entries at w_src; staged: n_s <= KMX_VSTAGE entries at s_src
+        const uint64_t w_src = swap ? p1src : src, s_src = swap ? src : p1src;
+        const uint32_t n_w = have ? (swap ? pcnt : c0) : 0u, n_s = have ? (swap ? c0 : pcnt) : 0u;
+        uint32_t P = n_s > 1 ? (1u << (32 - __clz(int(n_s - 1)))) : 1u;
+        P = max(P, uint32_t(__shfl_xor(int(P), KMX_VGROUP)));
+        P = max(P, uint32_t(__shfl_xor(int(P), 2 * KMX_VGROUP)));
+        P = uint32_t(__builtin_amdgcn_readfirstlane(int(P)));
+        uint32_t* __restrict__ arr = stage[wv][g];
+        // (the walked entry of this lane is asked for before the other bucket is staged: both travel together)
+        const uint32_t e = arena[w_src + min(gl, n_w ? n_w - 1u : 0u)];
+        {
+            const uint32_t last = n_s ? n_s - 1u : 0u;
+            const uint32_t* __restrict__ fil = arena + s_src;
+            for (uint32_t t0 = 0; t0 < P; t0 += 4 * KMX_VGROUP) {
+                const uint32_t t = t0 + 4u * gl;
+                u32x4 v = *reinterpret_cast<const u32x4_a4*>(fil + min(t, last));
+                v.x = t + 0 < n_s ? v.x : 0xFFFFFFFFu;
+                v.y = t + 1 < n_s ? v.y : 0xFFFFFFFFu;
+                v.z = t + 2 < n_s ? v.z : 0xFFFFFFFFu;
+                v.w = t + 3 < n_s ? v.w : 0xFFFFFFFFu;
+                *reinterpret_cast<u32x4*>(arr + t) = v;
+            }
+        }
+        // the walked entry of this lane as a start position p, and what must be found in the staged bucket
+        const bool live = gl < n_w && (!swap || e >= delta);            // (a start before the text is none)
+        const uint32_t p = swap ? e - delta : e;
+        const uint32_t x = swap ? p : e + delta;
+        unsigned long long* sw = swords[wv][g];
+        if (gl < MW) sw[gl] = 0;
+        wsync();
+        uint32_t pos = 0;
+        for (uint32_t st = P >> 1; st; st >>= 1) pos += arr[pos + st - 1] < x ? st : 0u;      // lower_bound :544-546 / binary_search :283
+        const bool ok = live && arr[pos] == x;
+        const uint32_t s16 = uint32_t(__ballot(ok) >> (KMX_VGROUP * g)) & 0xFFFFu;
+        // survivors ascend with the walked list; bit i of the mask = candidate i of the FIRST part's bucket
+        if (ok && d.stitch_hits) d.stitch_hits[wbase * 64 + uint32_t(__popc(s16 & lt_mask))] = p;
+        if (swap) {
+            if (ok) atomicOr(&sw[pos >> 6], 1ull << (pos & 63));
+            wsync();
+            if (have && gl <= c0 / 64) mask_words[wbase + gl] = sw[gl];            // n_bits/64 + 1 words (compressed_bitset.hpp:23)
+        } else if (have && gl == 0) {
+            mask_words[wbase] = s16;                                               // c0 <= 16 candidates: one word
+        }
+        if (have && gl == 0) d.cnt[q] = uint32_t(__popc(s16));
+        wsync();                                                        // stage[] / swords[] are the next round's
     }
 }
 
@@ -1196,16 +1445,20 @@ __global__ __launch_bounds__(KMX_VWIDE_BLOCK, 4) void k_validate_wide(const uint
     }
 }
 
-// k_validate_tiny — STITCH queries with at most KMX_VTINY candidates and KMX_VTINY entries in the filter part's bucket
-// (the regime of a large k: buckets of about one position, e.g. reads against a k = 20 index): one THREAD per query
-// does everything — filter by a linear scan, the further parts one after the other for the few survivors, the one
-// mask word, the survivor list, the count.  A 16-lane group per query would idle 15 lanes there.
+// k_validate_tiny — STITCH queries whose SHORTER bucket (first part's or filter part's) has at most KMX_VTINY entries and whose
+// longer one at most 2 KMX_VTINY (the regime of a large k: buckets of a few positions, e.g. 24-letter reads as two 12-mers):
+// one THREAD per query does everything — both buckets with six straight-line 16-byte loads (one memory round trip), the filter
+// as 8 x 16 register compares (the shorter list against the longer, whichever part it is: membership is symmetric), the
+// further parts one after the other for the few survivors, the one mask word, the survivor list, the count.  A 16-lane group
+// per query would idle 15 lanes there.
+// direct: a query whose survivors are ONE RUN of its first bucket (or none) leaves as a plain copy of that run — its src is
+// redirected there and k_fill treats it like an exact lookup (not when the candidate run is the caller's: KEEP_MASKS).
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate_tiny(const KmxIndexDev* __restrict__ ix,
                                                              const uint32_t* __restrict__ arena,
                                                              const uint8_t* __restrict__ qranks,
                                                              const uint64_t* __restrict__ qoff, QueryDesc d,
                                                              const uint32_t* __restrict__ list, uint64_t n_tiny,
-                                                             uint64_t* __restrict__ mask_words)
+                                                             uint64_t* __restrict__ mask_words, bool direct)
 {
     const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
     if (i >= n_tiny) return;
@@ -1215,26 +1468,49 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_tiny(const KmxIndexDev* 
     const uint64_t p1 = d.p1[q], p1src = d.key[q], wbase = d.aux[q];
     const bool more = (p1 & KMX_P1_MORE) != 0;
     const uint32_t pcnt = uint32_t(p1), delta = uint32_t(p1 >> 32) & KMX_P1_DELTA_MASK;
-    uint32_t filt[KMX_VTINY];
+    static_assert(KMX_VTINY == 8, "two 16-byte loads for the shorter bucket, four for the longer");
+    // (any element of the arena may be read 64 bytes wide: its allocation is padded)
+    const KMX_GLOBAL uint32_t* ar = as_global(arena);
+    // S: the shorter list (<= 8 entries), L: the longer (<= 16).  first_is_short: S is the first part's bucket — an entry s of S
+    // meets the entry s + delta of L; otherwise S is the filter part's and s - delta is looked for (s < delta wraps past every
+    // position: n + k - 1 < 2^32, kmer_index.hpp:169-170)
+    const bool first_is_short = c0 <= pcnt;
+    const uint64_t s_at = first_is_short ? src : p1src, l_at = first_is_short ? p1src : src;
+    const uint32_t n_s = first_is_short ? c0 : pcnt, n_l = first_is_short ? pcnt : c0;
+    const uint32_t shift = first_is_short ? delta : 0u - delta;
+    const u32x4 s0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + s_at), s1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + s_at + 4);
+    const u32x4 l0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + l_at), l1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + l_at + 4);
+    const u32x4 l2 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + l_at + 8), l3 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + l_at + 12);
+    const uint32_t sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const uint32_t lv[16] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w, l3.x, l3.y, l3.z, l3.w};
+    // bit i of alive <-> candidate i of the FIRST part's bucket survives
+    uint32_t alive = 0;
 #pragma unroll
-    for (uint32_t t = 0; t < KMX_VTINY; ++t) filt[t] = arena[t < pcnt ? p1src + t : p1src];      // straight-line loads
-    uint64_t word = 0;
-    uint32_t valid = 0;
-    for (uint32_t ci = 0; ci < c0; ++ci) {
-        const uint32_t p = arena[src + ci];
-        const uint32_t x = p + delta;
-        bool hit = false;
+    for (uint32_t a = 0; a < 8; ++a) {
+        uint32_t where = 0;                                                                        // bit b: S[a] meets L[b]
 #pragma unroll
-        for (uint32_t t = 0; t < KMX_VTINY; ++t) hit |= t < pcnt && filt[t] == x;                  // binary_search :283, lower_bound :544-546
-        if (hit && more) hit = stitch_parts_hold(ix, arena, qranks, qoff, q, p, 0u, 1u);
-        if (hit) {
-            word |= uint64_t(1) << ci;                                                             // bit i = word i>>6, bit i&63
-            if (d.stitch_hits) d.stitch_hits[wbase * 64 + valid] = p;
-            ++valid;
+        for (uint32_t b = 0; b < 16; ++b) where |= uint32_t(sv[a] + shift == lv[b]) << b;           // binary_search :283, lower_bound :544-546
+        where &= (1u << n_l) - 1u;
+        if (a < n_s) alive |= first_is_short ? uint32_t(where != 0) << a : where;
+    }
+    if (more && alive) {
+#pragma unroll 1
+        for (uint32_t left = alive; left; left &= left - 1) {
+            const uint32_t ci = uint32_t(__ffs(int(left))) - 1u;
+            if (!stitch_parts_hold(ix, arena, qranks, qoff, q, arena[src + ci], 0u, 1u)) alive &= ~(1u << ci);
         }
     }
-    mask_words[wbase] = word;                                                                      // c0 <= KMX_VTINY < 64: one word (compressed_bitset.hpp:23)
+    const uint32_t valid = uint32_t(__popc(alive));
+    mask_words[wbase] = alive;                                                                     // c0 <= 16 < 64: one word (compressed_bitset.hpp:23); bit i = word i>>6, bit i&63
     d.cnt[q] = valid;
+    const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u;
+    if (direct && (alive >> lo) == (1u << valid) - 1u) {
+        d.src[q] = src + lo;                                                                       // one run of the bucket (or nothing): copied where it lies
+    } else if (d.stitch_hits) {
+        uint32_t at = 0;
+#pragma unroll 1
+        for (uint32_t left = alive; left; left &= left - 1) d.stitch_hits[wbase * 64 + at++] = arena[src + uint32_t(__ffs(int(left))) - 1u];
+    }
 }
 
 // A long survivor list (a query inside a repeat of the text: thousands of candidates pass the filter) taken by the whole
@@ -1284,7 +1560,7 @@ __device__ void validate_more_wave(const KmxIndexDev* __restrict__ ix, const uin
                 } else {
                     uint64_t mm = m;
                     for (uint32_t w = 0; w <= e; ++w) {
-                        const KmxPlanEntry en = load_plan(ix, mm);
+                        const KmxPlanEntry en = load_plan_chain(ix, mm);
                         el = &ix->elems[en.elem];
                         k = el->k;
                         mm -= k;
@@ -1372,7 +1648,7 @@ __device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint
         } else {
             uint64_t mm = m;
             for (uint32_t w = 0; w <= e; ++w) {
-                const KmxPlanEntry en = load_plan(ix, mm);
+                const KmxPlanEntry en = load_plan_chain(ix, mm);
                 el = &ix->elems[en.elem];
                 k = el->k;
                 mm -= k;
@@ -2548,11 +2824,47 @@ __device__ __forceinline__ void merge_pair_table(KMX_LDS uint32_t* lpt, const KM
     if (lane == 0) lpt[4 * npairs + 2] = longest;
 }
 
-// E = ceil(len / (NT - ceil(R / 2))), rcp = floor(2^32 / E) + 1 (division by E as a multiplication: exact below 2^32 / E).
+// C chunks merged by one thread in LOCKSTEP (C independent chains of dependent LDS reads: a merge step waits a full LDS round
+// trip for the entry it has just chosen, so one chain per thread leaves the LDS pipe idle most of the time; with C chains the
+// round trips overlap).  Same steps as merge_chunk.
+template <int EMAX, bool CHECKED, int C>
+__device__ __forceinline__ void merge_chunks(const KMX_LDS uint32_t* (&pa)[C], const KMX_LDS uint32_t* (&pb)[C], const KMX_LDS uint32_t* const (&a_end)[C],
+                                             const KMX_LDS uint32_t* const (&b_end)[C], uint32_t E, uint32_t (&x)[C][EMAX])
+{
+    uint32_t va[C], vb[C];
+#pragma unroll
+    for (int u = 0; u < C; ++u) {
+        va[u] = *pa[u]; vb[u] = *pb[u];
+        if (CHECKED) {
+            va[u] = pa[u] < a_end[u] ? va[u] : KMX_PM_SENT;
+            vb[u] = pb[u] < b_end[u] ? vb[u] : KMX_PM_SENT;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < EMAX; ++j) {
+        if (uint32_t(j) < E) {                                    // uniform over the cooperating threads
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                const bool c = va[u] < vb[u];
+                x[u][j] = c ? va[u] : vb[u];
+                const KMX_LDS uint32_t* t = (c ? pa[u] : pb[u]) + 1;
+                uint32_t nv = *t;
+                if (CHECKED) nv = t < (c ? a_end[u] : b_end[u]) ? nv : KMX_PM_SENT;
+                pa[u] = c ? t : pa[u];
+                pb[u] = c ? pb[u] : t;
+                va[u] = c ? nv : va[u];
+                vb[u] = c ? vb[u] : nv;
+            }
+        }
+    }
+}
+
+// E = ceil(len / (C NT - ceil(R / 2))), rcp = floor(2^32 / E) + 1 (division by E as a multiplication: exact below 2^32 / E).
 // TSTRIDE > 0 (blocks of several waves; ptab holds one table of TSTRIDE words per round, ceil(log2 R) of them): the pair
 // tables of ALL rounds are written up front, wave r the table of round r, so that a round is partition - merge - barrier -
 // write back - barrier with no serial table phase in it; TSTRIDE == 0 (one wave): the table of a round is made at its start.
-template <int EMAX, int NT, int TSTRIDE, typename Sync>
+// C: chunks per thread and round (thread t takes chunks t, t + NT, ...), merged in lockstep — see merge_chunks.
+template <int EMAX, int NT, int TSTRIDE, int C, typename Sync>
 __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R, uint32_t len,
                                                uint32_t E, uint32_t rcp, uint32_t tid, Sync sync)
 {
@@ -2587,34 +2899,74 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
             const uint32_t longest = __builtin_amdgcn_readfirstlane(lpt[4 * npairs + 2]);
             while ((1u << steps) <= longest) ++steps;
         }
-        const bool active = tid < total;
-        uint32_t p = 0;
+        // this thread's C chunks of the round: chunk id -> its pair (a search over the pairs' first chunks), its diagonal
+        uint32_t p[C], s[C], mi[C], e[C], dg[C], nout[C], na[C], nb[C];
+#pragma unroll
+        for (int u = 0; u < C; ++u) p[u] = 0;
         {
             uint32_t step = 1;
             while (step < npairs) step <<= 1;
             for (step >>= 1; step; step >>= 1) {
-                const uint32_t cnd = p + step;
-                if (cnd < npairs && lpt[4 * cnd + 3] <= tid) p = cnd;
+#pragma unroll
+                for (int u = 0; u < C; ++u) {
+                    const uint32_t cnd = p[u] + step;
+                    if (cnd < npairs && lpt[4 * cnd + 3] <= tid + uint32_t(u) * NT) p[u] = cnd;
+                }
             }
         }
-        const uint32_t s = lpt[4 * p], mi = lpt[4 * p + 1], e = lpt[4 * p + 2], ch0 = lpt[4 * p + 3];
-        const uint32_t na = active ? mi - s : 0u, nb = active ? e - mi : 0u;
-        const uint32_t dg = active ? (tid - ch0) * E : 0u;         // the chunk's diagonal
-        const uint32_t nout = active ? min(E, na + nb - dg) : 0u;
-        const KMX_LDS uint32_t* pA = lb + (first ? s : s + 2 * p);
-        const KMX_LDS uint32_t* pB = lb + (first ? mi : mi + 2 * p + 1);
-        const uint32_t lo = merge_path_cut_lds(pA, na, pB, nb, dg, steps);
+        const KMX_LDS uint32_t* pA[C];
+        const KMX_LDS uint32_t* pB[C];
+#pragma unroll
+        for (int u = 0; u < C; ++u) {
+            const bool active = tid + uint32_t(u) * NT < total;
+            s[u] = lpt[4 * p[u]]; mi[u] = lpt[4 * p[u] + 1]; e[u] = lpt[4 * p[u] + 2];
+            const uint32_t ch0 = lpt[4 * p[u] + 3];
+            na[u] = active ? mi[u] - s[u] : 0u; nb[u] = active ? e[u] - mi[u] : 0u;
+            dg[u] = active ? (tid + uint32_t(u) * NT - ch0) * E : 0u;         // the chunk's diagonal
+            nout[u] = active ? min(E, na[u] + nb[u] - dg[u]) : 0u;
+            pA[u] = lb + (first ? s[u] : s[u] + 2 * p[u]);
+            pB[u] = lb + (first ? mi[u] : mi[u] + 2 * p[u] + 1);
+        }
+        // where every chunk's diagonal crosses the merge path: `steps` halving steps, the C searches in lockstep (branch-free: a
+        // candidate beyond the bracket reads a clamped entry and is refused)
+        uint32_t lo[C];
+        {
+            uint32_t hi[C];
+#pragma unroll
+            for (int u = 0; u < C; ++u) { lo[u] = dg[u] > nb[u] ? dg[u] - nb[u] : 0u; hi[u] = min(dg[u], na[u]); }
+            for (uint32_t st = steps ? 1u << (steps - 1) : 0u; st; st >>= 1) {
+                uint32_t av[C], bv[C], cand[C];
+#pragma unroll
+                for (int u = 0; u < C; ++u) {
+                    cand[u] = lo[u] + st;
+                    const uint32_t cc = min(cand[u], hi[u]);          // A[cand - 1] < B[dg - cand]: cand is not past the crossing
+                    av[u] = pA[u][int32_t(cc) - 1];
+                    bv[u] = (pB[u] + dg[u])[-int32_t(cc)];
+                }
+#pragma unroll
+                for (int u = 0; u < C; ++u) lo[u] = ((cand[u] <= hi[u]) & (av[u] < bv[u])) ? cand[u] : lo[u];
+            }
+        }
         // (the two kinds of round as two copies of "merge, barrier, write back": one set of registers each)
         auto round = [&](auto checked) {
-            uint32_t x[EMAX];
-            merge_chunk<EMAX, decltype(checked)::value>(pA + lo, pB + (dg - lo), lb + mi, lb + e, E, x);
-            sync();                                                // every read of the round is done
-            KMX_LDS uint32_t* o = lb + (s + p + dg);
+            uint32_t x[C][EMAX];
+            const KMX_LDS uint32_t* qa[C];
+            const KMX_LDS uint32_t* qb[C];
+            const KMX_LDS uint32_t* ea[C];
+            const KMX_LDS uint32_t* eb[C];
 #pragma unroll
-            for (int j = 0; j < EMAX; ++j)
-                if (uint32_t(j) < E) {
-                    if (uint32_t(j) < nout) o[j] = x[j];
-                }
+            for (int u = 0; u < C; ++u) { qa[u] = pA[u] + lo[u]; qb[u] = pB[u] + (dg[u] - lo[u]); ea[u] = lb + mi[u]; eb[u] = lb + e[u]; }
+            merge_chunks<EMAX, decltype(checked)::value, C>(qa, qb, ea, eb, E, x);
+            sync();                                                // every read of the round is done
+#pragma unroll
+            for (int u = 0; u < C; ++u) {
+                KMX_LDS uint32_t* o = lb + (s[u] + p[u] + dg[u]);
+#pragma unroll
+                for (int j = 0; j < EMAX; ++j)
+                    if (uint32_t(j) < E) {
+                        if (uint32_t(j) < nout[u]) o[j] = x[u][j];
+                    }
+            }
         };
         if (first) round(std::true_type{});
         else round(std::false_type{});
@@ -2881,7 +3233,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_small(const KmxIndex
         const uint32_t E = max(3u, ((len + (KMX_WAVE - (R + 1) / 2) - 1) / (KMX_WAVE - (R + 1) / 2)) | 1u);
         const uint32_t rcp = 0xFFFFFFFFu / E + 1;
         wsync();
-        merge_runs_lds<KMX_PM_WAVE_EMAX, KMX_WAVE, 0>(buf[wv] + 1, bnd[wv], ptab[wv], R, len, E, rcp, lane, wsync);
+        merge_runs_lds<KMX_PM_WAVE_EMAX, KMX_WAVE, 0, 1>(buf[wv] + 1, bnd[wv], ptab[wv], R, len, E, rcp, lane, wsync);
         uint32_t* __restrict__ seg = out + hit_off[q];
         for (uint32_t t = lane; t < len; t += KMX_WAVE) seg[t] = buf[wv][1 + t];
         wsync();                                                               // buf / bnd / ptab are the next query's
@@ -3015,11 +3367,17 @@ void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, 
 // survivor buffer (d.stitch_hits) those are finished by k_validate_more from the survivor lists, without one k_validate
 // checks them in line.
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
-                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t* mask_words)
+                     const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t n_short,
+                     uint64_t* mask_words, bool direct)
 {
     if (n_tiny)
         hipLaunchKernelGGL(k_validate_tiny, dim3(blocks_for(n_tiny, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, arena, qranks, qoff, d, tiny_list,
-                           n_tiny, mask_words);
+                           n_tiny, mask_words, direct && d.stitch_hits != nullptr);
+    if (n_short) {
+        const uint64_t swaves = (n_short + KMX_VGROUPS - 1) / KMX_VGROUPS;
+        const unsigned int sblocks = (unsigned int)std::min<uint64_t>((swaves + 3) / 4, 256 * 32);
+        hipLaunchKernelGGL(k_validate_short, dim3(sblocks ? sblocks : 1), dim3(KMX_BLOCK), 0, s, arena, d, n_short, mask_words);
+    }
     if (!n_stitch) return;
     uint64_t waves = (n_stitch + KMX_VGROUPS - 1) / KMX_VGROUPS;        // KMX_VGROUPS queries per wave
     unsigned int blocks = (unsigned int)std::min<uint64_t>((waves + 3) / 4, 256 * 32);
@@ -3153,9 +3511,13 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 // table the slice came from: up to RUNS of them are merged (merge_runs_lds), more are sorted by the bitonic network.
 // Two shapes: 1024 threads around 128 KB of LDS (one block per CU), and, for slices up to KMX_PSORT_MID_CAP positions,
 // 256 threads around 33 KB (four per CU: one block's staging and copy-out overlap the others' rounds).
+#ifndef KMX_PSB_CPT
+#define KMX_PSB_CPT 2          // chunks per thread and round in k_prefix_sort_block (merge_chunks: chains in lockstep)
+#endif
 template <int THREADS, int CAP, int RUNS>
 struct PsbShape {
-    static constexpr int EMAX = ((CAP + (THREADS - RUNS / 2) - 1) / (THREADS - RUNS / 2)) | 1;
+    static constexpr int CPT = KMX_PSB_CPT;
+    static constexpr int EMAX = ((CAP + (THREADS * CPT - RUNS / 2) - 1) / (THREADS * CPT - RUNS / 2)) | 1;
     static constexpr int WORDS = CAP + RUNS + EMAX + 5;      // staged chunk + sentinel cells + the reads of a chunk past its end
     static constexpr int TSTRIDE = 4 * (RUNS / 2 + 1);       // words of one round's pair table
     static constexpr int ROUNDS = RUNS <= 64 ? 6 : 7;        // ceil(log2 RUNS)
@@ -3213,8 +3575,9 @@ __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev
             for (uint32_t t = tid; t < n_stage; t += THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
             __syncthreads();
             if (merge) {
-                const uint32_t E = max(3u, ((c_len + (THREADS - (Rc + 1) / 2) - 1) / (THREADS - (Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
-                merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+                constexpr uint32_t CH = THREADS * Shape::CPT;                                     // chunks of a round
+                const uint32_t E = max(3u, ((c_len + (CH - (Rc + 1) / 2) - 1) / (CH - (Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
+                merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
             } else {
                 bitonic_lds(sbuf, n2, tid, uint32_t(THREADS), [] { __syncthreads(); });
             }
@@ -3528,6 +3891,19 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_narrow_offsets(const uint64_t* __
 void launch_all_kmers(hipStream_t s, uint32_t m, uint32_t sigma, uint64_t nq, uint8_t* d_qranks, uint64_t* d_qoff)
 {
     hipLaunchKernelGGL(k_all_kmers, dim3(blocks_for(nq + 1, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, m, sigma, nq, d_qranks, d_qoff);
+}
+
+// kmx_result_gather_device: the hit_off entries a part brought along count from the part's first hit; on the gathering device
+// they are moved behind the hits of the parts in front
+__global__ __launch_bounds__(KMX_BLOCK) void k_rebase_offsets(uint64_t* __restrict__ off, uint64_t n, uint64_t add)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (i < n) off[i] += add;
+}
+
+void launch_rebase_offsets(hipStream_t s, uint64_t* d_off, uint64_t n, uint64_t add)
+{
+    if (n && add) hipLaunchKernelGGL(k_rebase_offsets, dim3(blocks_for(n, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d_off, n, add);
 }
 
 void launch_narrow_offsets(hipStream_t s, const uint64_t* d_in, uint64_t n, uint32_t* d_out)

@@ -78,7 +78,12 @@ struct KmxElemDev {
 //   MULTI : `elem` is the element of the LAST summand of _optimal_nk_sum[m]; the
 //           summands before it are plan[m - k_last] (the DP builds list(q) =
 //           list(q-k) + [k], :434-435); nparts = number of summands.
-enum { KMX_SCHEME_NONE = 0, KMX_SCHEME_SINGLE = 1, KMX_SCHEME_MULTI = 2 };
+//   REPLANNED (engine planner table only): a MULTI entry of the reference (elem / nparts as above, so that the chains of longer
+//           sums still walk through it) that the ENGINE answers as SINGLE on element nparts >> KMX_PLAN_ALT_SHIFT — the largest k
+//           of the index: a sum of two 10-mers is also two overlapping 12-mers, whose buckets are sigma^2 times shorter.
+enum { KMX_SCHEME_NONE = 0, KMX_SCHEME_SINGLE = 1, KMX_SCHEME_MULTI = 2, KMX_SCHEME_REPLANNED = 3 };
+#define KMX_PLAN_ALT_SHIFT 11                                   // nparts < 2^11 (range <= 65535 * 9, summands >= 9 letters ... see make_fast_plan_entries)
+#define KMX_PLAN_NPARTS_MASK ((1u << KMX_PLAN_ALT_SHIFT) - 1u)
 struct KmxPlanEntry {
     uint8_t scheme;
     uint8_t elem;
@@ -126,6 +131,8 @@ struct KmxIndexDev {
 // which holds 0xFFFFFFFF ("do not store") for a whole tile of slots: 4096 words + the 1024 bytes above.
 #define KMX_ARENA_PAD (4096 * 4 + 1024)
 #define KMX_VTINY 8             // k_validate_tiny: one thread per STITCH query up to this many candidates / filter entries
+#define KMX_VSHORT 16           // k_validate_short: two-part STITCH queries whose SHORTER bucket has at most this many entries (one per lane of a
+                                // 16-lane group) and whose longer one fits a group's stage — the shorter side is walked, whichever part it is
 #define KMX_PSORT_MAX_RUNS 32   // run boundaries kept per query by k_prefix_sort_small (its merge paths need 4 of them)
 #define KMX_PSORT_CAP 2048
 // ... up to KMX_PSORT_BLOCK_CAP positions (any number of runs) by one 1024-thread block (bitonic sort in
@@ -204,5 +211,6 @@ enum {
     KMX_CTR_PREFIX_MERGE = 14, // small PREFIX queries of the merge class (KMX_PSORT_IS_MERGE): k_prefix_merge_small has work
     KMX_CTR_PREFIX_MID = 15,   // of KMX_CTR_PREFIX_BIG: slices of at most KMX_PSORT_MID_CAP positions (k_prefix_sort_block's 256-thread variant)
     KMX_CTR_PREFIX_PLAIN = 0,  // PREFIX queries answered by ONE list (nothing to sort: on no work list)
-    KMX_CTR_COUNT = 16
+    KMX_CTR_STITCH_SHORT = 16, // two-part STITCH queries whose shorter bucket has at most KMX_VSHORT entries (listed in QueryDesc::short_list)
+    KMX_CTR_COUNT = 20
 };

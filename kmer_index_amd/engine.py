@@ -25,6 +25,7 @@ EXPORTS = [
     "kmx_result_view", "kmx_result_masks", "kmx_result_free", "kmx_stats_enable", "kmx_stats_get",
     "kmx_stats_reset", "kmx_debug_words", "kmx_last_error", "kmx_status_string", "kmx_version",
     "kmx_index_devices", "kmx_result_parts", "kmx_result_part_view_device",
+    "kmx_index_bucket_host", "kmx_index_levels", "kmx_result_gather_device",
 ]
 
 
@@ -106,6 +107,12 @@ def lib():
         L.kmx_result_parts.argtypes = [vp, P(u32)]
         L.kmx_result_part_view_device.restype = C.c_int
         L.kmx_result_part_view_device.argtypes = [vp, u32, P(C.c_int32), P(u64), P(u64), P(vp), P(vp), P(vp)]
+        L.kmx_index_bucket_host.restype = C.c_int
+        L.kmx_index_bucket_host.argtypes = [vp, u32, vp, P(vp), P(u32)]
+        L.kmx_index_levels.restype = C.c_int
+        L.kmx_index_levels.argtypes = [vp, vp]
+        L.kmx_result_gather_device.restype = C.c_int
+        L.kmx_result_gather_device.argtypes = [vp, C.c_int32, P(vp), P(vp), P(vp)]
         L.kmx_stats_enable.restype = C.c_int
         L.kmx_stats_enable.argtypes = [vp, C.c_int]
         L.kmx_stats_get.restype = C.c_int
@@ -235,6 +242,12 @@ class Result:
         t_pos = torch.as_tensor(_Arr(b, c["n_hits"], "<i4"), device=device) if c["n_hits"] else torch.empty(0, dtype=torch.int32, device=device)
         return t_off, t_pos
 
+    def gather_device(self, dst_device):
+        """kmx_result_gather_device: (d_hit_off, d_positions, d_status) of the whole batch in the HBM of dst_device."""
+        a, b, s = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        _check(lib().kmx_result_gather_device(self._h, int(dst_device), C.byref(a), C.byref(b), C.byref(s)))
+        return a.value, b.value, s.value
+
     def masks(self):
         c = self.counts()
         a, b, cc, d = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
@@ -324,6 +337,21 @@ class Index:
         d = (C.c_int32 * KMX_MAX_DEVICES)()
         _check(lib().kmx_index_devices(self._h, C.byref(n), d))
         return [int(d[i]) for i in range(n.value)]
+
+    def levels(self):
+        """kmx_index_levels: prefix levels built per element (info()["ks"] order)."""
+        lv = np.zeros(KMX_MAX_KS, np.uint32)
+        _check(lib().kmx_index_levels(self._h, lv.ctypes.data))
+        return lv[:len(self.ks)].tolist()
+
+    def bucket_host(self, k, ranks):
+        """kmx_index_bucket_host: the bucket of one k-mer out of the host arena (search_k, kmer_index.hpp:183-190); None on a miss."""
+        ranks = np.ascontiguousarray(ranks, np.uint8)
+        if ranks.size != k:
+            raise ValueError("bucket_host: k letters expected")
+        p, n = C.c_void_p(), C.c_uint32()
+        _check(lib().kmx_index_bucket_host(self._h, int(k), ranks.ctypes.data, C.byref(p), C.byref(n)))
+        return _view(p.value, n.value, np.uint32).copy() if p.value else None
 
     def extend_query_size_range(self, new_maximum):
         _check(lib().kmx_index_extend_query_size_range(self._h, new_maximum))

@@ -74,7 +74,54 @@ void run_test(std::size_t text_size, std::uint64_t seed)
         CHECK(single_kmer.template search_k<k>(text.begin() + s).to_vector() == naive(text, a));
         CHECK(multi_kmer.template search_k<k + 2>(text.begin() + s).to_vector() == naive(text, b));
     }
+    // search_k with the reference's OWN shape (kmer_index.hpp:183-190): a borrowed `const std::vector<position_t>*` into the index,
+    // nullptr on a miss — used the way kmer_index::search uses it at :516-527 / :532-555 (parts looked up one by one, then the first
+    // part's positions cross-referenced against the second's)
+    {
+        std::size_t s = (seed * 52361) % (text_size - 2 * k);
+        std::vector<alphabet_t> query(text.begin() + s, text.begin() + s + 2 * k);
+        std::vector<const std::vector<std::uint32_t>*> nk_positions;
+        std::size_t last_k = 0;
+        for (std::size_t current_k : {k, k})
+        {
+            const auto* pos = single_kmer.search_k(query.begin() + last_k);
+            if (pos)
+                nk_positions.push_back(pos);
+            else
+                break;
+            last_k = current_k;
+        }
+        CHECK(nk_positions.size() == 2);
+        if (nk_positions.size() == 2)
+        {
+            std::vector<alphabet_t> a(query.begin(), query.begin() + k), b(query.begin() + k, query.end());
+            CHECK(*nk_positions[0] == naive(text, a) && *nk_positions[1] == naive(text, b));
+            CHECK(single_kmer.search_k(query.begin()) == nk_positions[0]);                      // the SAME borrowed vector every time
+            std::vector<std::uint32_t> stitched;
+            for (std::size_t start_pos_i = 0; start_pos_i < nk_positions.front()->size(); ++start_pos_i)
+            {
+                const std::uint32_t previous_pos = nk_positions.front()->at(start_pos_i);
+                const auto* current = nk_positions.at(1);
+                auto it = std::lower_bound(current->begin(), current->end(), previous_pos + std::uint32_t(k));
+                if (it != current->end() && *it == previous_pos + k) stitched.push_back(previous_pos);
+            }
+            CHECK(stitched == naive(text, query));
+        }
+        auto random_kmer = generate_sequence<alphabet_t>(seed * 977 + 5, k);
+        const auto* maybe = single_kmer.search_k(random_kmer.begin());
+        auto truth = naive(text, random_kmer);
+        CHECK((maybe == nullptr) == truth.empty());
+        if (maybe) CHECK(*maybe == truth);
+        // an index with several ks: the element is named, as the reference does internally (:388)
+        std::vector<alphabet_t> c(text.begin() + s, text.begin() + s + k + 2);
+        const auto* pos2 = multi_kmer.template element<k + 2>().search_k(text.begin() + s);
+        CHECK(pos2 != nullptr && *pos2 == naive(text, c));
+        const auto* pos0 = multi_kmer.template element<k>().search_k(text.begin() + s);
+        std::vector<alphabet_t> d(text.begin() + s, text.begin() + s + k);
+        CHECK(pos0 != nullptr && *pos0 == naive(text, d));
+    }
     // ... and the batch overload
+    CHECK(multi_kmer.get_mask_mode() == decltype(multi_kmer)::mask_mode::lazy);     // the default: hit lists only, masks on demand
     auto batch = multi_kmer.search(queries);
     CHECK(batch.size() == queries.size());
     for (std::size_t i = 0; i < queries.size(); ++i)
@@ -90,6 +137,7 @@ void run_test(std::size_t text_size, std::uint64_t seed)
         }
         std::vector<std::uint32_t> via_iter(batch[i].begin(), batch[i].end());
         CHECK(via_iter == truth);
+        CHECK(batch[i].bypasses_bitmask() || !batch[i].mask_is_resident());      // nothing of the mask has crossed PCIe yet
         if (!batch[i].bypasses_bitmask())
         {
             // zero-copy view: candidates filtered by the mask == to_vector()
@@ -136,7 +184,25 @@ void run_test(std::size_t text_size, std::uint64_t seed)
         CHECK(lean[i].size() == 0 || lean[i].bypasses_bitmask());
     }
     CHECK(multi_kmer.search(queries[0]).to_vector() == batch[0].to_vector());
+    // the reference's result object fetched WITH the search (keep_masks(true)): what the lazy results fetched one by one
     multi_kmer.keep_masks(true);
+    auto eager = multi_kmer.search(queries);
+    CHECK(eager.size() == queries.size());
+    for (std::size_t i = 0; i < queries.size(); ++i)
+    {
+        CHECK(eager[i].to_vector() == batch[i].to_vector() && eager[i].mask_is_resident());
+        CHECK(eager[i].bypasses_bitmask() == batch[i].bypasses_bitmask());
+        if (!eager[i].bypasses_bitmask())
+        {
+            CHECK(eager[i].n_candidates() == batch[i].n_candidates() && eager[i].bitmask().words() == batch[i].bitmask().words());
+            if (!(eager[i].n_candidates() == batch[i].n_candidates() && eager[i].bitmask().words() == batch[i].bitmask().words()))
+                std::printf("  query %zu (m = %zu): eager %zu candidates, %zu words, first word %llx; lazy %zu candidates, %zu words, first word %llx\n", i, queries[i].size(),
+                            eager[i].n_candidates(), eager[i].bitmask().words().size(), (unsigned long long)eager[i].bitmask().words()[0],
+                            batch[i].n_candidates(), batch[i].bitmask().words().size(), (unsigned long long)batch[i].bitmask().words()[0]);
+            CHECK(eager[i].n_candidates() == 0 || eager[i].candidates() == batch[i].candidates());      // the same run of the host arena
+        }
+    }
+    multi_kmer.set_mask_mode(decltype(multi_kmer)::mask_mode::lazy);
 }
 
 int main()

@@ -139,9 +139,11 @@ def test_header_is_plain_c(tmp_path):
 
 
 def test_engine_planner_table_differs_from_the_reference_only_where_it_may(engine):
-    """kmx_plan_engine (the table searches run on unless KEEP_MASKS / REFERENCE_PLAN): same as the reference's planner for
-    every length it answers from one k with m <= k, for its multi-k lengths (reported as 0) and wherever a rest could reach the
-    sub-k fan-out guard (kmer_index.hpp:119-122 via :234) on either choice; otherwise the LARGEST k <= m of the index."""
+    """kmx_plan_engine (the table searches run on unless KEEP_MASKS / REFERENCE_PLAN): the reference's planner for every length it
+    answers from one k with m <= k and wherever a rest could reach the sub-k fan-out guard (kmer_index.hpp:119-122 via :234) on
+    either choice; otherwise the LARGEST k of the index that fits — also for the reference's multi-k sums (re-planned: a sum of
+    summands is also a run of parts of ONE k with the k-mer that ends the query as the last of them; 0 = the sum is kept: an exact
+    length the scheme owns, :529-530, or every k risky)."""
     rng = np.random.default_rng(12)
     cases = [([8, 10, 12], 4), ([10], 4), ([5], 20), ([9, 10], 4), ([4, 6], 27), ([14, 20, 31], 4), ([3, 4, 5], 15), ([13, 16], 4), ([7, 12], 20)]
     for _ in range(20):
@@ -150,14 +152,20 @@ def test_engine_planner_table_differs_from_the_reference_only_where_it_may(engin
         kmax = {2: 40, 4: 31, 5: 27, 15: 16, 20: 14, 27: 13}[sigma]
         cases.append((sorted(set(int(v) for v in rng.integers(1, kmax + 1, n_k))), sigma))
     limit = 10_000_000
-    changed = 0
+    changed = replanned = 0
     for ks, sigma in cases:
         R = 400
         multi, nk_sum = engine.plan(ks, R)
         used = engine.plan_engine(ks, sigma, R)
         for m in range(1, R):
+            risky = lambda k: (m % k) != 0 and sigma ** (k - m % k) > limit      # noqa: E731
             if multi[m] and len(ks) > 1:
-                assert used[m] == 0, (ks, sigma, m)
+                if len(nk_sum[m]) == 1:
+                    assert used[m] == 0, (ks, sigma, m)                   # an exact length of a high k: served as an exact lookup
+                else:
+                    best = max([k for k in ks if k < m and not risky(k)], default=0)
+                    assert used[m] == best, (ks, sigma, m, int(used[m]), best)
+                    replanned += int(best != 0)
                 continue
             k_ref = nk_sum[m][0]
             k_eng = int(used[m])
@@ -165,11 +173,10 @@ def test_engine_planner_table_differs_from_the_reference_only_where_it_may(engin
             if m <= k_ref or len(ks) == 1:
                 assert k_eng == k_ref, (ks, sigma, m)
                 continue
-            risky = lambda k: (m % k) != 0 and sigma ** (k - m % k) > limit      # noqa: E731
             if risky(k_ref):
                 assert k_eng == k_ref, (ks, sigma, m)
                 continue
             best = max([k for k in ks if k <= m and k > k_ref and not risky(k)] + [k_ref])
             assert k_eng == best, (ks, sigma, m, k_ref, k_eng, best)
             changed += int(k_eng != k_ref)
-    assert changed > 100
+    assert changed > 100 and replanned > 100

@@ -55,3 +55,39 @@ def test_fallback_paths_in_a_child_process(env):
     e.update(env)
     res = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=e)
     assert res.returncode == 0 and "fallback child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+OOM_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from kmer_index_amd import engine, synth
+from tests.helpers import make_queries
+
+text = synth.ranks(1003, 300_000, 4)
+idx = engine.Index(text, 4, [8, 10, 12])
+q, off = make_queries(text, 4, [8, 10, 12, 13, 20, 22], 2000, seed=5)
+nq = off.size - 1
+res = idx.search(q, off)                       # KMX_HOST_CHUNK makes this a chunk-streamed search; one chunk search reports out of memory
+got = res.host()
+n_parts = res.n_parts()
+res.close()
+print("oom child ok", n_parts, int(got[0][nq]), int(np.bitwise_xor.reduce(got[1].astype(np.uint64) * np.arange(1, got[1].size + 1, dtype=np.uint64))))
+"""
+
+
+@pytest.mark.gpu
+def test_chunked_search_survives_an_out_of_memory_with_one_worker():
+    """after an out-of-memory in a chunk-streamed host batch the retry runs with ONE set of device buffers at the
+    SAME chunk size (it used to come back to the freed second worker and halve down to failure).  The allocation failure is
+    injected (KMX_TEST_INJECT_CHUNK_OOM = the n-th chunk search); the result must equal the uninjected one's, chunk for chunk."""
+    outs = []
+    for inject in (None, "2", "3"):
+        e = dict(os.environ)
+        e["KMX_HOST_CHUNK"] = "3000"
+        if inject:
+            e["KMX_TEST_INJECT_CHUNK_OOM"] = inject
+        res = subprocess.run([sys.executable, "-c", OOM_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=e)
+        assert res.returncode == 0 and "oom child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+        outs.append(res.stdout.strip().splitlines()[-1].split()[3:])
+    assert outs[0] == outs[1] == outs[2], outs           # same number of chunks (no halving), same hits

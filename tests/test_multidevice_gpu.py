@@ -285,3 +285,58 @@ def test_no_device_memory_is_leaked(engine, monkeypatch):
     for _ in range(9):
         last = one_round()
     assert abs(first - last) <= 8 << 20, (first, last)
+
+
+def _dev_array(ptr, n, dtype, device):
+    """n items at device pointer `ptr` as a numpy array (through a torch tensor aliasing the memory)."""
+    import torch
+
+    class _Arr:
+        def __init__(self, p, count, typestr):
+            self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": typestr, "data": (int(p), False), "version": 2}
+
+    if n == 0:
+        return np.zeros(0, dtype)
+    typestr = {np.uint64: "<i8", np.uint32: "<i4", np.uint8: "|u1"}[dtype]
+    t = torch.as_tensor(_Arr(ptr, n, typestr), device=f"cuda:{device}")
+    return t.cpu().numpy().view(dtype).copy()
+
+
+@pytest.mark.parametrize("devs", [[0, 0], [0, 0, 0, 0]])
+def test_gather_device_returns_the_single_device_arrays_byte_for_byte(engine, devs):
+    """kmx_result_gather_device (SURVEY 8e step 3 behind the C-ABI): the parts of a multi-replica result gathered into one set of
+    device arrays == what one device returns for the whole batch.  One ordinal listed several times on a 1-GPU box (the peer
+    copies are then device-local; the displacements, the rebase kernel and the stream ordering are the ones N GPUs use)."""
+    text = synth.ranks(1003, 300_000, 4)
+    ks = [8, 10, 12]
+    q, off = make_queries(text, 4, [5, 8, 9, 10, 12, 13, 20, 22, 24, 31], 500, seed=17)
+    nq = off.size - 1
+    one = engine.Index(text, 4, ks, device=0)
+    want = one.search(q, off).host()
+    many = engine.Index(text, 4, ks, devices=devs)
+    for flags in (engine.SEARCH_DEFAULT, engine.SEARCH_COUNT_ONLY):
+        rn = many.search(q, off, flags=flags)
+        assert rn.n_parts() == len(devs)
+        for rep in range(2):                                           # (the second gather reuses the result's buffers)
+            d_off, d_pos, d_st = rn.gather_device(0)
+            assert np.array_equal(_dev_array(d_off, nq + 1, np.uint64, 0), want[0])
+            assert np.array_equal(_dev_array(d_st, nq, np.uint8, 0), want[2])
+            if flags == engine.SEARCH_COUNT_ONLY:
+                assert not d_pos
+            else:
+                assert np.array_equal(_dev_array(d_pos, int(want[0][nq]), np.uint32, 0), want[1])
+        rn.close()
+    # a handful of queries (everything on the first replica), and a single-device result gathered where it lies
+    few = many.search(q[:int(off[40])], off[:41])
+    d_off, d_pos, d_st = few.gather_device(0)
+    assert np.array_equal(_dev_array(d_off, 41, np.uint64, 0), want[0][:41])
+    assert np.array_equal(_dev_array(d_pos, int(want[0][40]), np.uint32, 0), want[1][:int(want[0][40])])
+    few.close()
+    r1 = one.search(q, off)
+    a, b, s = r1.gather_device(0)
+    assert (a, b, s) == r1.device_ptrs()
+    with pytest.raises(engine.KmxError):
+        r1.gather_device(99)
+    r1.close()
+    many.close()
+    one.close()

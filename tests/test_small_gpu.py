@@ -247,3 +247,65 @@ def test_latency_path_against_the_oracle_directly(engine, orc, sigma, ks):
                 assert took_small == 1, "a handful of queries must take the one-launch path"
         assert idx.stats()["k_small"]["launches"] >= 4
         idx.close()
+
+
+def test_bucket_host_is_search_k_without_a_device_round_trip(engine, orc):
+    """kmx_index_bucket_host (kmer_index_element::search_k, kmer_index.hpp:183-190): the bucket of one k-mer out of the host
+    arena == the exact occurrence list, None on a miss; dense and open tables, device-built and host-flattened elements."""
+    text = synth.ranks(77, 200_000, 4)
+    for table, host_flatten, ks in ((engine.TABLE_DENSE, False, [6, 10]), (engine.TABLE_OPEN, False, [10, 14]), (engine.TABLE_OPEN, True, [9]),
+                                    (engine.TABLE_AUTO, False, [20])):
+        idx = engine.Index(text, 4, ks, table=table, keep_host_arena=True, host_flatten=host_flatten)
+        launches_before = sum(v["launches"] for v in idx.stats().values())
+        idx.stats_enable(True)
+        for k in ks:
+            n_miss = 0
+            for t in range(60):
+                if t % 2:
+                    s0 = (t * 7919) % (text.size - k)
+                    kmer = text[s0:s0 + k].copy()
+                else:
+                    kmer = synth.ranks(5000 + t, k, 4)
+                got = idx.bucket_host(k, kmer)
+                want = orc.naive_scan(text, kmer)
+                if want.size == 0:
+                    assert got is None
+                    n_miss += 1
+                else:
+                    assert got is not None and np.array_equal(got, want), (table, k, t)
+            assert k < 10 or n_miss > 0
+        assert sum(v["launches"] for v in idx.stats().values()) == launches_before      # no kernel ran for any of it
+        with pytest.raises(engine.KmxError):
+            idx.bucket_host(7, text[:7])                                  # no element for this k
+        with pytest.raises(engine.KmxError):
+            idx.bucket_host(ks[0], np.full(ks[0], 9, np.uint8))          # a letter outside the alphabet
+        idx.close()
+    plain = engine.Index(text, 4, [8])
+    with pytest.raises(engine.KmxError):
+        plain.bucket_host(8, text[:8])                                    # built without keep_host_arena
+    plain.close()
+
+
+def test_levels_are_reported_and_old_abi_callers_get_none(engine):
+    """kmx_index_levels says what kmx_options.prefix_levels got; a caller compiled against KMX_VERSION 1 / 2 (shorter
+    struct_size, cannot name the field) pays for no level."""
+    import ctypes as C
+    text = synth.ranks(78, 300_000, 4)
+    idx = engine.Index(text, 4, [8, 10])
+    assert idx.levels() == [2, 1] or idx.levels()[0] >= 1, idx.levels()   # (how far a level goes also depends on the planner: k - L must still be this element's)
+    assert idx.memory()["prefix_levels"] > 0
+    idx.close()
+    none = engine.Index(text, 4, [8, 10], prefix_levels=-1)
+    assert none.levels() == [0, 0] and none.memory()["prefix_levels"] == 0
+    none.close()
+    L = engine.lib()
+    ks = np.array([8, 10], np.uint32)
+    for old_size in (engine.Options.n_devices.offset, engine.Options.prefix_levels.offset):
+        o = engine.Options()
+        o.struct_size = old_size
+        o.device = -1
+        h = C.c_void_p()
+        assert L.kmx_index_build(text.ctypes.data, text.size, 4, ks.ctypes.data, 2, C.byref(o), C.byref(h)) == 0
+        lv = np.zeros(32, np.uint32)
+        assert L.kmx_index_levels(h, lv.ctypes.data) == 0 and not lv.any()
+        L.kmx_index_free(h)
