@@ -71,7 +71,12 @@ namespace kmer::detail
             _fetched = true;
             std::vector<std::uint64_t> words;
             _lazy->fetch(_lazy_id, _candidates, _n_candidates, words);
-            if (_candidates == nullptr) _n_candidates = 0;
+            if (_candidates == nullptr)
+            {
+                _n_candidates = 0;                                    // the reference's default result (kmer_index.hpp:204,224,524)
+                _bitmask = compressed_bitset<std::uint_fast64_t>(0, true);
+                return;
+            }
             if (words.size() < _n_candidates / 64 + 1) words.resize(_n_candidates / 64 + 1, 0);
             _bitmask = compressed_bitset<std::uint_fast64_t>(_n_candidates, words.data());
         }

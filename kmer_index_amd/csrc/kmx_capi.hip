@@ -192,6 +192,7 @@ struct kmx_index {
     KmxIndexDev h_header{};              // host copy of the device header (holds device pointers)
     kmx::FillVariant fill_variant{12, true};   // 3072-slot tiles (12 gathers in flight per thread), non-temporal stores
     bool rec32 = true;                   // every arena index fits 31 bits
+    bool tiny_cells = false;             // some element has cells and at most four positions per key on average (k_lookup: 8 queries per thread)
     bool broken = false;                 // a failed kmx_index_extend_query_size_range left the replicas' planner tables inconsistent
     std::vector<uint32_t> host_arena;   // optional host mirror of the position arena
     Stats stats;
@@ -245,6 +246,7 @@ struct kmx_result {
     bool small_valid = false;              // the result of the last search lives in the mailbox only (no device buffers were written)
     bool host_valid = false, host_masks_valid = false;
     bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
+    bool last_had_pairs = false;           // the previous batch held cross-referenced queries: k_lookup's variant (kmx_search_batch_device)
     std::shared_ptr<ResultPool> pool;      // where kmx_result_free parks this result (set by the search that made it)
     SearchCtx ctx;                         // the half-done search of a KMX_SEARCH_ASYNC call (search_finish completes it)
     hipEvent_t done = nullptr;             // recorded behind the first half's counter read-back
@@ -565,6 +567,7 @@ static kmx_status install_images_impl(std::vector<kmx::ElemImage>& images, const
             }
             if (ce != hipSuccess) { fail(ce == hipErrorOutOfMemory ? KMX_ERR_OUT_OF_MEMORY : KMX_ERR_HIP, std::string("cells: ") + hipGetErrorString(ce)); return bail(KMX_ERR_HIP); }
             el.cnt8 = static_cast<const uint8_t*>(p);
+            if (im.npos <= 4 * im.n_keys) ix->tiny_cells = true;
             ix->bytes_cells += ((im.n_keys << cell_shift[i]) * 4) + im.n_keys;
             el.cell_base = cell_base[i];
             el.cell_shift = cell_shift[i];
@@ -608,7 +611,7 @@ static kmx_status replicate_index(const kmx_index* src, int device, kmx_index** 
     ix->device = device;
     ix->n = src->n; ix->sigma = src->sigma; ix->range = src->range;
     ix->ks = src->ks; ix->table_kinds = src->table_kinds; ix->elem_sizes = src->elem_sizes; ix->tail = src->tail;
-    ix->fill_variant = src->fill_variant; ix->rec32 = src->rec32;
+    ix->fill_variant = src->fill_variant; ix->rec32 = src->rec32; ix->tiny_cells = src->tiny_cells;
     ix->bytes_positions = src->bytes_positions; ix->bytes_aligned = src->bytes_aligned; ix->bytes_cells = src->bytes_cells; ix->bytes_levels = src->bytes_levels;
     auto bail = [&](kmx_status s) { std::string keep = g_err; kmx_index_free(ix); g_err = keep; return s; };
     hipError_t e = hipSetDevice(device);
@@ -1465,7 +1468,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     HIP_TRY(r->stitch_list.ensure(nq * 4));
     HIP_TRY(r->prefix_list.ensure(nq * 4));
     HIP_TRY(r->short_list.ensure(nq * 4));
-    HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(nq), kmx::lookup_blocks(nq)) * 8));
+    HIP_TRY(r->bsum.ensure(std::max(kmx::scan_blocks(nq), kmx::lookup_blocks(nq, 4)) * 8));
     if (r->ctr.cap < 2 * KMX_CTR_COUNT * sizeof(unsigned long long)) {
         // two counter blocks per handle, used in turn: the scan of a batch zeroes the block of the next one
         HIP_TRY(r->ctr.ensure(2 * KMX_CTR_COUNT * sizeof(unsigned long long)));
@@ -1486,7 +1489,13 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     auto* ctr_next = r->ctr.as<unsigned long long>() + (r->ctr_phase ^ 1u) * KMX_CTR_COUNT;
     const KmxIndexDev* dix = header_for(ix, flags);
 
-    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), flags); });
+    // The k_lookup variant, from what the previous batch on this handle held (results do not depend on the choice): batches with
+    // two-part cross-referenced queries take the variant that interleaves and finishes them; without, the lean one — with eight
+    // queries per thread on an index of tiny cells (a query there is one byte of a table and one 32-byte cell).
+    static const int force_items = getenv("KMX_LOOKUP_ITEMS") ? atoi(getenv("KMX_LOOKUP_ITEMS")) : 0;      // (tuning / tests: 4 | 8, or -4: 4 with pairs)
+    const bool pairs = force_items ? force_items == -4 : r->last_had_pairs;
+    const int items = force_items ? (force_items == 8 ? 8 : 4) : (!pairs && ix->tiny_cells) ? 8 : 4;
+    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, items, pairs, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), flags); });
     // speculative scan: already final when the batch holds no STITCH query
     // The downsweep also records the first query of every output tile (k_partition's job) when the
     // tile table kept from an earlier batch is large enough — the steady state.
@@ -1499,7 +1508,7 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     bool published = false;
     timed(ix, K_SCAN, s, [&] {
         published = kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS, tile,
-                                           tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, true,
+                                           tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, items,
                                            kmx::CounterPub{ctr, ctr_next, r->h_ctr});
     });
     r->ctr_clean = published;
@@ -1560,7 +1569,7 @@ static kmx_status search_finish(kmx_result* r)
     auto scan_hits = [&] {                                     // (k_validate changed the counts: a full scan)
         timed(ix, K_SCAN, s, [&] {
             kmx::launch_scan_tiles(s, d.cnt, nq, r->bsum.as<uint64_t>(), r->hit_off.as<uint64_t>(), ctr + KMX_CTR_TOTAL_HITS, tile,
-                                   tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, false);
+                                   tile_cap >= 2 ? tile_cap - 1 : 0, tile_cap >= 2 ? r->tile_q.as<uint32_t>() : nullptr, 0);
         });
     };
     const uint64_t n_stitch_groups = r->h_ctr[KMX_CTR_STITCH], n_stitch_tiny = r->h_ctr[KMX_CTR_STITCH_TINY];   // front / back of stitch_list
@@ -1568,6 +1577,7 @@ static kmx_status search_finish(kmx_result* r)
     const uint64_t n_stitch_pending = n_stitch_groups + n_stitch_tiny + n_stitch_short;                 // still to be validated
     r->n_stitch = n_stitch_pending + r->h_ctr[KMX_CTR_STITCH_RESOLVED];                                  // (k_lookup resolved the others itself)
     r->last_had_stitch = n_stitch_pending != 0;
+    r->last_had_pairs = r->n_stitch != 0;                        // (resolved ones included: they are what the pairs variant of k_lookup is for)
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
     r->n_prefix = n_prefix_small + n_prefix_big + r->h_ctr[KMX_CTR_PREFIX_PLAIN];
     r->n_error = r->h_ctr[KMX_CTR_ERROR];
@@ -1752,6 +1762,7 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
             r->small_valid = true;
             r->quiesced = true;
             r->last_had_stitch = false;
+            r->last_had_pairs = false;
             r->pool = ix->pool;                                 // (kmx_result_view_device asks it whether the index is still there)
             return KMX_OK;
         }

@@ -24,8 +24,10 @@ struct QueryDesc {
                             // k_validate and copied out by k_fill; nullptr -> k_compact decodes the masks instead
 };
 
-uint64_t lookup_blocks(uint64_t nq);
-void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+// k_lookup variants: items = queries per thread (4 or 8), pairs = the interleaved pass takes two-part cross-referenced queries
+// (pairs implies items == 4).  block_hits receives lookup_blocks(nq, items) sums: the first level of the scan behind it.
+uint64_t lookup_blocks(uint64_t nq, int items);
+void launch_lookup(hipStream_t s, int items, bool pairs, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits, uint32_t flags);
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t n_short,
@@ -74,8 +76,8 @@ struct CounterPub {
 };
 // returns true when the publication was done by the scan (the fused-spine path), false when the caller has to copy / reset
 bool launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
-                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums,
-                       const CounterPub& pub = CounterPub());
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, int lookup_items,
+                       const CounterPub& pub = CounterPub());   // lookup_items: bsum holds the sums of the k_lookup variant with that many queries per thread (0: none)
 FillVariant effective_fill_variant(const FillVariant& v, bool rec32);
 uint64_t fill_tile(const FillVariant& v);
 void launch_partition(hipStream_t s, const uint64_t* off, uint64_t nq, uint64_t tile, uint64_t n_tiles, uint32_t* tile_q);

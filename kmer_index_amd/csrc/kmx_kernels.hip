@@ -32,9 +32,6 @@
 
 #define KMX_BLOCK 256
 #define KMX_WAVE 64
-#ifndef KMX_LOOKUP_ITEMS
-#define KMX_LOOKUP_ITEMS 4     // queries per thread in k_lookup
-#endif
 #define KMX_PSORT_PAIR_CAP 512   // k_prefix_sort_small: slices up to this length are merged pairwise from registers
 #ifndef KMX_PSORT_MULTIWAY_RUNS
 #define KMX_PSORT_MULTIWAY_RUNS 4   // k_prefix_sort_small: multi-way rank pass up to this many runs, bitonic beyond
@@ -507,22 +504,47 @@ struct BlockCounters {
     unsigned int base_stitch, base_stitch_tiny, base_stitch_short, base_prefix, base_prefix_big;
     unsigned long long base_words;
     unsigned int max_fan_exp;       // largest j with sigma^j <= KMX_SUBK_FANOUT_LIMIT (the guard of kmer_index.hpp:119-122 as an exponent)
+    unsigned int small_keys;        // every element's key space allows hash16<true>
 };
 
-// rank-hash (kmer_index.hpp:56-73) of the first `len` <= 16 letters of a 16-byte block that is already in registers
+// rank-hash (kmer_index.hpp:56-73) of the first `len` <= 16 letters of a 16-byte block that is already in registers.
+// The letters are moved to the END of the block (a 128-bit shift by 16 - len bytes: the bytes in front of them read 0, and
+// Horner's rule over leading zeros stays 0), so that the sixteen steps are straight-line code without a per-letter predicate: one
+// byte extract, one compare and one multiply-add per letter.  SMALL (block-uniform): every partial sum fits 24 bits and the
+// hash 32 — the multiply-add is the full-rate 24-bit one (a 32-bit integer multiply issues at a quarter of the rate).
+template <bool SMALL>
 __device__ __forceinline__ bool hash16(const u32x4_a1& w, uint32_t len, uint32_t sigma, uint64_t& h)
 {
     uint64_t lo = uint64_t(w[0]) | (uint64_t(w[1]) << 32), hi = uint64_t(w[2]) | (uint64_t(w[3]) << 32);
-    uint64_t acc = 0;
-    bool ok = true;
-    for (uint32_t j = 0; j < len; ++j) {
-        const uint32_t r = uint32_t(lo & 0xFF);
-        lo = (lo >> 8) | (hi << 56);
-        hi >>= 8;
-        ok &= r < sigma;
-        acc = acc * sigma + r;
+    {
+        const uint32_t sh = (16u - len) * 8u;                         // 0 .. 128 bits to the "left" (towards the last byte)
+        const uint32_t s6 = sh & 63u;
+        const uint64_t carry = s6 ? lo >> (64u - s6) : 0;
+        const uint64_t hi1 = (hi << s6) | carry, lo1 = lo << s6;      // shift by sh mod 64 ...
+        hi = sh >= 128u ? 0 : sh >= 64u ? lo1 : hi1;                  // ... and by whole 64-bit words
+        lo = sh >= 64u ? 0 : lo1;
     }
-    h = acc;
+    const uint32_t wd[4] = {uint32_t(lo), uint32_t(lo >> 32), uint32_t(hi), uint32_t(hi >> 32)};
+    bool ok = true;
+    if (SMALL) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t r = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            ok &= r < sigma;
+            acc = __umul24(acc, sigma) + r;
+        }
+        h = acc;
+    } else {
+        uint64_t acc = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t r = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
+            ok &= r < sigma;
+            acc = acc * sigma + r;
+        }
+        h = acc;
+    }
     return ok;
 }
 // at(hash) (kmer_index.hpp:76-84) in two halves, so that the loads of several queries can be in flight together:
@@ -571,9 +593,14 @@ __device__ __forceinline__ Run probe_finish(const KmxElemDev* el, uint64_t h, co
 #define KMX_PLAN_LDS 256        // planner entries kept in LDS by k_lookup (queries shorter than this take its interleaved passes)
 
 #ifndef KMX_LOOKUP_OCC
-#define KMX_LOOKUP_OCC 5        // waves per SIMD k_lookup is compiled for
+#define KMX_LOOKUP_OCC 4        // waves per SIMD the two-part variant of k_lookup is compiled for (5 spills: measured slower)
 #endif
-__global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxIndexDev* __restrict__ ix,
+// ITEMS: queries per thread (4; 8 for indexes of tiny cells, where a query is one byte of a table and one cell: twice the
+// queries per wave keep more of those short round trips in flight).  PAIRS: the interleaved pass also takes the two-part
+// cross-referenced queries (and finishes the tiny ones); without it they go through pass 2 one by one — the same results, and a
+// leaner kernel for batches that hold none.  The host picks the variant from what the previous batch on the handle held.
+template <int ITEMS, bool PAIRS>
+__global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 : 5)) void k_lookup(const KmxIndexDev* __restrict__ ix,
                                                       const uint8_t* __restrict__ qranks,
                                                       const uint64_t* __restrict__ qoff, uint64_t nq,
                                                       QueryDesc d, unsigned long long* __restrict__ ctr,
@@ -592,6 +619,13 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
         unsigned int j = 0;
         while (j < 63 && ix->pw[j + 1] <= KMX_SUBK_FANOUT_LIMIT) ++j;
         bc.max_fan_exp = j;
+        // hash16<true>: every partial Horner sum below 2^24 (sigma^(k-1) <= 2^24) and the hash below 2^32, for every element
+        unsigned int small = ix->sigma < (1u << 24) ? 1u : 0u;
+        for (uint32_t e = 0; e < ix->n_ks; ++e) {
+            const uint64_t nk = ix->elems[e].n_keys;
+            if (nk > (uint64_t(1) << 32) || nk / ix->sigma > (uint64_t(1) << 24)) small = 0;
+        }
+        bc.small_keys = small;
     }
     {
         const uint32_t n_words = ix->n_ks * uint32_t(sizeof(KmxElemDev) / 8);
@@ -603,16 +637,18 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
     const uint8_t* __restrict__ qend = qranks + qoff[nq];
     __syncthreads();
 
-    // a block serves KMX_LOOKUP_ITEMS * 256 queries so that the (returning) global atomics of the
+    // a block serves ITEMS * 256 queries so that the (returning) global atomics of the
     // work-list bookkeeping are paid once per 1024 queries
-    uint8_t kinds[KMX_LOOKUP_ITEMS];
-    unsigned int locs[KMX_LOOKUP_ITEMS];
-    unsigned long long locw[KMX_LOOKUP_ITEMS];
-    bool done[KMX_LOOKUP_ITEMS];
+    uint8_t kinds[ITEMS];
+    unsigned int locs[ITEMS];
+    unsigned long long locw[ITEMS];
+    bool done[ITEMS];
     uint64_t my_hits = 0;
     const uint32_t sigma = ix->sigma, range = ix->range;
+    const bool small_keys = __builtin_amdgcn_readfirstlane(int(bc.small_keys)) != 0;
     const uint8_t* __restrict__ dummy = reinterpret_cast<const uint8_t*>(ix);     // always >= 64 readable bytes
 
+    unsigned int my_resolved = 0, my_err = 0, my_none = 0;     // (outcomes counted per thread, one LDS atomic each at the end)
     // One query's descriptor out, with the block-aggregated bookkeeping of the work lists (LDS counters now, one global atomic
     // per counter and block later).  Everything that is not a plain exact lookup ends here: STITCH queries are sorted into the
     // tiny / short / general classes of the validation kernels, PREFIX ones into the classes of the merge kernels.
@@ -650,9 +686,9 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
                 }
             }
         }
-        if (resolved) atomicAdd(&bc.n_resolved, 1u);
-        if (status != KMX_Q_OK) atomicAdd(&bc.n_error, 1u);
-        if (status == KMX_Q_OK && kind == KMX_KIND_NONE) atomicAdd(&bc.n_none, 1u);
+        my_resolved += resolved;
+        my_err += status != KMX_Q_OK;
+        my_none += status == KMX_Q_OK && kind == KMX_KIND_NONE;
         kinds[it] = !resolved ? kind : uint8_t(KMX_KIND_NONE);    // (only the work-list bookkeeping at the end reads this)
         locs[it] = loc;
         locw[it] = loc_words;
@@ -662,9 +698,11 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
         d.kind[q] = kind;
         d.status[q] = status;
         if (kind == KMX_KIND_STITCH) {
-            d.c0[q] = c0;
-            d.key[q] = key;
-            d.p1[q] = p1;
+            if (!resolved) {                                      // (a resolved query is a plain copy from here on: nobody asks for its parts)
+                d.c0[q] = c0;
+                d.key[q] = key;
+                d.p1[q] = p1;
+            }
         } else if (kind == KMX_KIND_PREFIX) {
             d.c0[q] = c0;
             d.aux[q] = aux;
@@ -672,12 +710,12 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
         }
     };
 
-    uint64_t qb[KMX_LOOKUP_ITEMS];
-    uint32_t qm[KMX_LOOKUP_ITEMS];
-    uint32_t praw[KMX_LOOKUP_ITEMS];
+    uint64_t qb[ITEMS];
+    uint32_t qm[ITEMS];
+    uint32_t praw[ITEMS];
 #pragma unroll
-    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-        const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
         const uint64_t qq = q < nq ? q : nq - 1;
         qb[it] = qoff[qq];
         const uint64_t mlen = qoff[qq + 1] - qb[it];
@@ -687,7 +725,7 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
         locw[it] = 0;
     }
 #pragma unroll
-    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it)
+    for (int it = 0; it < ITEMS; ++it)
         praw[it] = plan_effective(((const KMX_GLOBAL uint32_t*)ix->plan)[min(qm[it], range - 1)]);
 
     // ---- pass 1: the plain exact lookup (m == k <= 16, :198-205) and cross-referenced queries of exactly TWO parts with
@@ -695,20 +733,20 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
     // (:515-555) — with the thread's queries INTERLEAVED: all offsets, then all plan entries, then all letter loads (both parts),
     // then all probes (both parts) — one memory round trip per phase instead of one per query, part and phase.
     {
-        uint32_t eab[KMX_LOOKUP_ITEMS];                    // element of the first part | element of the second << 8 | offset of the second << 16
-        bool two[KMX_LOOKUP_ITEMS];
-        u32x4_a1 wa[KMX_LOOKUP_ITEMS], wb[KMX_LOOKUP_ITEMS];
+        uint32_t eab[ITEMS];                    // element of the first part | element of the second << 8 | offset of the second << 16
+        bool two[ITEMS];
+        u32x4_a1 wa[ITEMS], wb[ITEMS];
         unsigned int n_none = 0, n_err = 0;
 #pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
             const uint32_t m = qm[it], scheme = praw[it] & 0xFF, e = (praw[it] >> 8) & 0xFF;
             const uint32_t kb = elems_s[e].k;
             const bool live = q < nq && m > 0 && m < range;
             const bool one = live && scheme == KMX_SCHEME_SINGLE && kb == m && m <= 16 && qranks + qb[it] + 16 <= qend;
             bool t = false;
             uint32_t ea = e, off = 0;
-            if (live && !one && m < KMX_PLAN_LDS) {
+            if (PAIRS && live && !one && m < KMX_PLAN_LDS) {
                 if (scheme == KMX_SCHEME_SINGLE) {
                     const uint32_t rest = m < 2 * kb ? m - kb : 0u;                   // (m > kb checked below)
                     t = m > kb && m <= 2 * kb && kb <= 16 && (rest == 0 || kb - rest <= bc.max_fan_exp);   // (:119-122 via :234 stays with pass 2)
@@ -727,44 +765,51 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
             two[it] = t;
             eab[it] = ea | (e << 8) | (off << 16);
             wa[it] = *reinterpret_cast<const u32x4_a1*>(done[it] ? qranks + qb[it] : dummy);
-            wb[it] = *reinterpret_cast<const u32x4_a1*>(t ? qranks + qb[it] + off : dummy);
+            if (PAIRS) wb[it] = *reinterpret_cast<const u32x4_a1*>(t ? qranks + qb[it] + off : dummy);
         }
-        uint64_t ha[KMX_LOOKUP_ITEMS], hb[KMX_LOOKUP_ITEMS];
-        bool oka[KMX_LOOKUP_ITEMS], okb[KMX_LOOKUP_ITEMS];
-        u32x4_a1 pa[KMX_LOOKUP_ITEMS], pb[KMX_LOOKUP_ITEMS];
+        uint64_t ha[ITEMS], hb[ITEMS];
+        bool oka[ITEMS], okb[ITEMS];
+        u32x4_a1 pa[ITEMS], pb[ITEMS];
 #pragma unroll
-        for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+        for (int it = 0; it < ITEMS; ++it) {
             const KmxElemDev* ela = &elems_s[eab[it] & 0xFF];
             const KmxElemDev* elb = &elems_s[(eab[it] >> 8) & 0xFF];
-            oka[it] = hash16(wa[it], done[it] ? ela->k : 0u, sigma, ha[it]);
-            okb[it] = hash16(wb[it], two[it] ? elb->k : 0u, sigma, hb[it]);
+            okb[it] = true; hb[it] = 0;
+            if (small_keys) {
+                oka[it] = hash16<true>(wa[it], done[it] ? ela->k : 0u, sigma, ha[it]);
+                if (PAIRS) okb[it] = hash16<true>(wb[it], two[it] ? elb->k : 0u, sigma, hb[it]);
+            } else {
+                oka[it] = hash16<false>(wa[it], done[it] ? ela->k : 0u, sigma, ha[it]);
+                if (PAIRS) okb[it] = hash16<false>(wb[it], two[it] ? elb->k : 0u, sigma, hb[it]);
+            }
             // first probe: dense -> the table entries of h; open -> the slot {key, off, cnt}; both as one 16-byte load
             pa[it] = *(const KMX_GLOBAL u32x4_a1*)((done[it] && oka[it]) ? probe_first_addr(ela, ha[it]) : reinterpret_cast<const char*>(dummy));
-            pb[it] = *(const KMX_GLOBAL u32x4_a1*)((two[it] && okb[it]) ? probe_first_addr(elb, hb[it]) : reinterpret_cast<const char*>(dummy));
+            if (PAIRS) pb[it] = *(const KMX_GLOBAL u32x4_a1*)((two[it] && okb[it]) ? probe_first_addr(elb, hb[it]) : reinterpret_cast<const char*>(dummy));
         }
-        // The buckets are known.  An exact lookup leaves right away; a pair whose two buckets hold at most KMX_VTINY positions
-        // each (large k: 24-letter reads as two 12-mers) is finished HERE: both buckets are read (2 x 32 bytes each, straight-line
-        // — any element of the arena may be read 32 bytes wide, its allocation is padded) and when the surviving start positions
-        // are one run of the first bucket the query leaves as a plain copy of that run — no descriptor round trip through a
-        // validation kernel, no mask words (not with KEEP_MASKS: the words are the point there).  Two queries' bucket loads are
-        // in flight at a time.
+        // The buckets are known.  An exact lookup leaves right away; a pair of the TINY class — the shorter bucket at most KMX_VTINY
+        // positions, the longer at most 2 KMX_VTINY (large k: 24-letter reads as two 12-mers) — is finished HERE: both buckets are
+        // read (32 + 64 bytes, straight-line — any element of the arena may be read 64 bytes wide, its allocation is padded), the
+        // shorter list is looked up in the longer (membership is symmetric, whichever part it is), and when the surviving start
+        // positions are one run of the first bucket the query leaves as a plain copy of that run — no descriptor round trip
+        // through a validation kernel, no mask words (not with KEEP_MASKS: the words are the point there).  Two queries' bucket
+        // loads are in flight at a time.
         struct Pend {
-            bool two, tiny;
+            bool two, tiny, first_is_short;
             uint8_t kind, status;
             uint64_t src, key, p1;
             uint32_t c0, off, pc;
-            u32x4 a0, a1, b0, b1;
+            u32x4 s0, s1, l0, l1, l2, l3;
         };
         const KMX_GLOBAL uint32_t* ar = as_global(ix->arena);
         auto stage1 = [&](int it) -> Pend {
-            Pend P;
-            P.two = false; P.tiny = false; P.kind = KMX_KIND_NONE; P.status = KMX_Q_OK; P.src = P.key = P.p1 = 0; P.c0 = P.off = P.pc = 0;
-            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            Pend P{};
+            P.two = false; P.tiny = false; P.first_is_short = true; P.kind = KMX_KIND_NONE; P.status = KMX_Q_OK; P.src = P.key = P.p1 = 0; P.c0 = P.off = P.pc = 0;
+            const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
             Run ra{0, 0}, rb{0, 0};
             if (done[it]) {
                 const KmxElemDev* ela = &elems_s[eab[it] & 0xFF];
                 if (oka[it]) ra = probe_finish(ela, ha[it], pa[it]);
-                if (!two[it]) {
+                if (!PAIRS || !two[it]) {
                     const uint8_t status = oka[it] ? KMX_Q_OK : KMX_Q_BAD_RANK;
                     n_err += status != KMX_Q_OK;
                     n_none += status == KMX_Q_OK && !ra.cnt;
@@ -788,55 +833,73 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
                         P.kind = KMX_KIND_STITCH; P.src = ra.src; P.c0 = ra.cnt; P.key = rb.src; P.off = off; P.pc = rb.cnt;
                         P.p1 = (uint64_t(off) << 32) | rb.cnt;
                         if (!(flags & KMX_SEARCH_KEEP_MASKS) && stitch_goes_big(ra.cnt, rb.cnt)) P.p1 |= KMX_P1_BIG;
-                        P.tiny = !(flags & KMX_SEARCH_KEEP_MASKS) && ra.cnt <= KMX_VTINY && rb.cnt <= KMX_VTINY;
+                        P.tiny = !(flags & KMX_SEARCH_KEEP_MASKS) && min(ra.cnt, rb.cnt) <= KMX_VTINY && max(ra.cnt, rb.cnt) <= 2 * KMX_VTINY;
+                        P.first_is_short = ra.cnt <= rb.cnt;
                     }
                 }
             }
-            static_assert(KMX_VTINY == 8, "two 16-byte loads per bucket");
-            const uint64_t sa = P.tiny ? ra.src : 0, sb = P.tiny ? rb.src : 0;
-            P.a0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sa); P.a1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sa + 4);
-            P.b0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sb); P.b1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sb + 4);
+            static_assert(KMX_VTINY == 8, "two 16-byte loads for the shorter bucket, four for the longer");
+            if (!PAIRS) return P;
+            const uint64_t sa = !P.tiny ? 0 : P.first_is_short ? ra.src : rb.src, la = !P.tiny ? 0 : P.first_is_short ? rb.src : ra.src;
+            P.s0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sa); P.s1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + sa + 4);
+            P.l0 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + la); P.l1 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + la + 4);
+            P.l2 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + la + 8); P.l3 = *reinterpret_cast<const KMX_GLOBAL u32x4_a4*>(ar + la + 12);
             return P;
         };
         auto stage2 = [&](int it, const Pend& P) {
-            if (!P.two) return;
-            const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+            if (!PAIRS || !P.two) return;
+            const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
             uint64_t src = P.src;
             uint32_t cnt = 0;
             bool resolved = false;
             if (P.tiny) {
-                const uint32_t av[8] = {P.a0.x, P.a0.y, P.a0.z, P.a0.w, P.a1.x, P.a1.y, P.a1.z, P.a1.w};
-                const uint32_t bv[8] = {P.b0.x, P.b0.y, P.b0.z, P.b0.w, P.b1.x, P.b1.y, P.b1.z, P.b1.w};
-                uint32_t alive = 0;
+                // S: the shorter list, L: the longer.  An entry s of S meets the entry s + shift of L: shift = +off when S is the first
+                // part's bucket, -off when it is the second's (s < off wraps past every position: n + k - 1 < 2^32, :169-170)
+                const uint32_t sv[8] = {P.s0.x, P.s0.y, P.s0.z, P.s0.w, P.s1.x, P.s1.y, P.s1.z, P.s1.w};
+                const uint32_t lv[16] = {P.l0.x, P.l0.y, P.l0.z, P.l0.w, P.l1.x, P.l1.y, P.l1.z, P.l1.w, P.l2.x, P.l2.y, P.l2.z, P.l2.w, P.l3.x, P.l3.y, P.l3.z, P.l3.w};
+                const uint32_t n_s = P.first_is_short ? P.c0 : P.pc, n_l = P.first_is_short ? P.pc : P.c0;
+                const uint32_t shift = P.first_is_short ? P.off : 0u - P.off;
+                uint32_t met = 0;                                  // bit a: S[a] is met in L (binary_search :283, lower_bound :544-546)
+                uint32_t last = 0;                                 // the last such entry, as a start position's partner in L
 #pragma unroll
-                for (uint32_t i = 0; i < 8; ++i) {
+                for (uint32_t a = 0; a < 8; ++a) {
+                    const uint32_t x = sv[a] + shift;
                     bool hit = false;
 #pragma unroll
-                    for (uint32_t j = 0; j < 8; ++j) hit |= j < P.pc && av[i] + P.off == bv[j];      // binary_search :283, lower_bound :544-546
-                    alive |= uint32_t(hit && i < P.c0) << i;
+                    for (uint32_t b = 0; b < 16; ++b) hit |= b < n_l && x == lv[b];
+                    hit = hit && a < n_s;
+                    met |= uint32_t(hit) << a;
+                    last = hit ? x : last;
                 }
-                const uint32_t lo = alive ? uint32_t(__ffs(int(alive))) - 1u : 0u, len = uint32_t(__popc(alive));
-                if ((alive >> lo) == (1u << len) - 1u) {       // one run of the bucket (or nothing)
-                    resolved = true;
-                    src = P.src + lo;
-                    cnt = len;
+                const uint32_t n_met = uint32_t(__popc(met));
+                if (P.first_is_short) {
+                    const uint32_t lo = met ? uint32_t(__ffs(int(met))) - 1u : 0u;
+                    if ((met >> lo) == (1u << n_met) - 1u) {       // one run of the first bucket (or nothing)
+                        resolved = true; src = P.src + lo; cnt = n_met;
+                    }
+                } else if (n_met <= 1) {
+                    // the walked list was the SECOND part's: the one survivor's place in the first bucket (= L) is its rank there
+                    uint32_t rank = 0;
+#pragma unroll
+                    for (uint32_t b = 0; b < 16; ++b) rank += uint32_t(b < n_l && lv[b] < last);
+                    resolved = true; src = P.src + (n_met ? rank : 0u); cnt = n_met;
                 }
             }
             emit(it, q, P.kind, P.status, src, 0, P.key, P.p1, cnt, P.c0, resolved);
         };
-        static_assert(KMX_LOOKUP_ITEMS == 4 || KMX_LOOKUP_ITEMS == 8, "the two-in-flight schedule below");
+        static_assert(ITEMS == 4 || ITEMS == 8, "the two-in-flight schedule below");
         {
             Pend p0 = stage1(0);
             Pend p1 = stage1(1);
 #pragma unroll
-            for (int it = 2; it < KMX_LOOKUP_ITEMS; it += 2) {
+            for (int it = 2; it < ITEMS; it += 2) {
                 stage2(it - 2, p0);
                 p0 = stage1(it);
                 stage2(it - 1, p1);
                 p1 = stage1(it + 1);
             }
-            stage2(KMX_LOOKUP_ITEMS - 2, p0);
-            stage2(KMX_LOOKUP_ITEMS - 1, p1);
+            stage2(ITEMS - 2, p0);
+            stage2(ITEMS - 1, p1);
         }
         if (n_err) atomicAdd(&bc.n_error, n_err);
         if (n_none) atomicAdd(&bc.n_none, n_none);
@@ -844,9 +907,9 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
 
     // ---- pass 2: everything else (other lengths, long queries, more parts), one query at a time
 #pragma unroll 1
-    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
+    for (int it = 0; it < ITEMS; ++it) {
         if (done[it]) continue;
-        const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+        const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
         if (q >= nq) continue;
         const uint64_t b = qoff[q];
         const uint64_t m = qoff[q + 1] - b;
@@ -855,6 +918,9 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
         emit(it, q, lo.kind, lo.status, lo.src, lo.aux, lo.key, lo.p1, lo.cnt, lo.c0, lo.resolved);
     }
 
+    if (my_resolved) atomicAdd(&bc.n_resolved, my_resolved);
+    if (my_err) atomicAdd(&bc.n_error, my_err);
+    if (my_none) atomicAdd(&bc.n_none, my_none);
     for (int off = 32; off > 0; off >>= 1) my_hits += __shfl_xor(my_hits, off);
     if (lane_id() == 0 && my_hits) atomicAdd(&bc.hits, (unsigned long long)my_hits);
     __syncthreads();
@@ -882,8 +948,8 @@ __global__ __launch_bounds__(KMX_BLOCK, KMX_LOOKUP_OCC) void k_lookup(const KmxI
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < KMX_LOOKUP_ITEMS; ++it) {
-        const uint64_t q = (uint64_t(blockIdx.x) * KMX_LOOKUP_ITEMS + it) * KMX_BLOCK + threadIdx.x;
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
         if (kinds[it] == KMX_KIND_STITCH) {
             d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
             if (locs[it] & 0x80000000u) d.stitch_list[nq - 1 - (bc.base_stitch_tiny + (locs[it] & 0x3FFFFFFFu))] = uint32_t(q);
@@ -2327,18 +2393,17 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_spine(uint64_t* __restrict__
 // SPINE: there is no spine launch — bsum holds the plain block sums of k_scan_reduce and every block adds up the
 // sums in front of it itself (at most KMX_SCAN_FUSED_SPINE_BLOCKS of them: a few KB out of L2); the last block
 // also writes the grand total.
-// SPINE == 2: the same with the sums k_lookup left behind, one per KMX_BLOCK * KMX_LOOKUP_ITEMS queries (n_fine of
-// them, KMX_SCAN_FINE per scan tile) — no reduce launch either.
-#define KMX_SCAN_FINE (KMX_SCAN_TILE / (KMX_BLOCK * KMX_LOOKUP_ITEMS))
+// SPINE == 2: the same with the sums k_lookup left behind, one per KMX_BLOCK * (queries per thread of the variant that ran)
+// queries (n_fine of them, fine_per_tile = KMX_SCAN_TILE / that per scan tile) — no reduce launch either.
 template <bool TILES, int SPINE>
 __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restrict__ in, uint64_t n,
                                                          const uint64_t* __restrict__ bsum,
                                                          uint64_t* __restrict__ out, uint64_t tile,
                                                          uint64_t n_tiles_cap, uint32_t* __restrict__ tile_q,
                                                          unsigned long long* __restrict__ total_out, uint64_t n_fine,
-                                                         CounterPub pub)
+                                                         CounterPub pub, uint32_t fine_per_tile)
 {
-    static_assert(KMX_SCAN_TILE % (KMX_BLOCK * KMX_LOOKUP_ITEMS) == 0, "a scan tile is a whole number of lookup blocks");
+    static_assert(KMX_SCAN_TILE % (KMX_BLOCK * 8) == 0 && KMX_SCAN_TILE % (KMX_BLOCK * 4) == 0, "a scan tile is a whole number of lookup blocks");
     // The block's 4096 items as KMX_SCAN_ROWS rows of 1024: in row r thread t owns items r*1024 + 4t .. 4t+3 —
     // one coalesced 16-byte load and two 16-byte stores per row.  The rows are scanned together (one set of
     // wave shuffles and barriers for all of them).
@@ -2378,7 +2443,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_scan_down(const uint32_t* __restr
     uint64_t row_base;
     if constexpr (SPINE != 0) {
         __shared__ uint64_t part[KMX_BLOCK / KMX_WAVE];
-        const uint64_t mine = SPINE == 2 ? uint64_t(blockIdx.x) * KMX_SCAN_FINE : uint64_t(blockIdx.x);   // sums in front of this block
+        const uint64_t mine = SPINE == 2 ? uint64_t(blockIdx.x) * fine_per_tile : uint64_t(blockIdx.x);   // sums in front of this block
         uint64_t acc = 0;
         for (uint64_t i = threadIdx.x; i < mine; i += KMX_BLOCK) acc += bsum[i];
         for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
@@ -3353,13 +3418,15 @@ static inline unsigned int blocks_for(uint64_t n, uint64_t per_block)
     return (unsigned int)(b ? b : 1);
 }
 
-uint64_t lookup_blocks(uint64_t nq) { return blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS); }
+uint64_t lookup_blocks(uint64_t nq, int items) { return blocks_for(nq, uint64_t(KMX_BLOCK) * uint64_t(items)); }
 
-void launch_lookup(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
+void launch_lookup(hipStream_t s, int items, bool pairs, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits, uint32_t flags)
 {
-    hipLaunchKernelGGL(k_lookup, dim3(blocks_for(nq, KMX_BLOCK * KMX_LOOKUP_ITEMS)), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr,
-                       block_hits, flags);
+    const dim3 grid(blocks_for(nq, uint64_t(KMX_BLOCK) * uint64_t(items))), block(KMX_BLOCK);
+    if (pairs) hipLaunchKernelGGL((k_lookup<4, true>), grid, block, 0, s, ix, qranks, qoff, nq, d, ctr, block_hits, flags);
+    else if (items == 8) hipLaunchKernelGGL((k_lookup<8, false>), grid, block, 0, s, ix, qranks, qoff, nq, d, ctr, block_hits, flags);
+    else hipLaunchKernelGGL((k_lookup<4, false>), grid, block, 0, s, ix, qranks, qoff, nq, d, ctr, block_hits, flags);
 }
 
 // The STITCH work list holds n_stitch queries from its front and n_tiny "tiny" ones from its back (list_end = one past
@@ -3412,38 +3479,40 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, 
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
         hipLaunchKernelGGL((k_scan_down<false, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                           (uint32_t*)nullptr, total_out, uint64_t(0), CounterPub());
+                           (uint32_t*)nullptr, total_out, uint64_t(0), CounterPub(), 0u);
         return;
     }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
     hipLaunchKernelGGL((k_scan_down<false, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                       (uint32_t*)nullptr, total_out, uint64_t(0), CounterPub());
+                       (uint32_t*)nullptr, total_out, uint64_t(0), CounterPub(), 0u);
 }
 
 // scan + first-query-of-every-tile in one downsweep; tile_q must hold n_tiles_cap + 1 entries (nullptr: plain scan).
 // lookup_sums: bsum already holds k_lookup's per-block sums of `in` (lookup_blocks(n) of them) — no reduce launch.
 bool launch_scan_tiles(hipStream_t s, const uint32_t* in, uint64_t n, uint64_t* bsum, uint64_t* out,
-                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, bool lookup_sums,
+                       unsigned long long* total_out, uint64_t tile, uint64_t n_tiles_cap, uint32_t* tile_q, int lookup_items,
                        const CounterPub& pub)
 {
     const unsigned int nb = blocks_for(n, KMX_SCAN_TILE);
+    const bool lookup_sums = lookup_items != 0;
     if (lookup_sums && nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
-        const uint64_t n_fine = lookup_blocks(n);
+        const uint64_t n_fine = lookup_blocks(n, lookup_items);
+        const uint32_t fine = uint32_t(KMX_SCAN_TILE / (KMX_BLOCK * lookup_items));
         if (tile_q)
-            hipLaunchKernelGGL((k_scan_down<true, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, n_fine, pub);
+            hipLaunchKernelGGL((k_scan_down<true, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, n_fine, pub, fine);
         else
             hipLaunchKernelGGL((k_scan_down<false, 2>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, uint64_t(1), uint64_t(0),
-                               (uint32_t*)nullptr, total_out, n_fine, pub);
+                               (uint32_t*)nullptr, total_out, n_fine, pub, fine);
         return pub.host != nullptr;
     }
     if (!tile_q) { launch_scan(s, in, n, bsum, out, total_out); return false; }
     hipLaunchKernelGGL(k_scan_reduce, dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum);
     if (nb <= KMX_SCAN_FUSED_SPINE_BLOCKS) {
-        hipLaunchKernelGGL((k_scan_down<true, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0), CounterPub());
+        hipLaunchKernelGGL((k_scan_down<true, 1>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0), CounterPub(), 0u);
         return false;
     }
     hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(KMX_BLOCK), 0, s, bsum, uint64_t(nb), total_out);
-    hipLaunchKernelGGL((k_scan_down<true, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0), CounterPub());
+    hipLaunchKernelGGL((k_scan_down<true, 0>), dim3(nb), dim3(KMX_BLOCK), 0, s, in, n, bsum, out, tile, n_tiles_cap, tile_q, total_out, uint64_t(0), CounterPub(), 0u);
     return false;
 }
 
@@ -3512,7 +3581,10 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 // Two shapes: 1024 threads around 128 KB of LDS (one block per CU), and, for slices up to KMX_PSORT_MID_CAP positions,
 // 256 threads around 33 KB (four per CU: one block's staging and copy-out overlap the others' rounds).
 #ifndef KMX_PSB_CPT
-#define KMX_PSB_CPT 2          // chunks per thread and round in k_prefix_sort_block (merge_chunks: chains in lockstep)
+#define KMX_PSB_CPT 1          // chunks per thread and round in k_prefix_sort_block (merge_chunks: chains in lockstep; 2 measured slower:
+#endif                         // the merge-path searches double and the LDS pipe, not its latency, is what the rounds wait for)
+#ifndef KMX_PBK_MIN_RUNS
+#define KMX_PBK_MIN_RUNS 4     // chunks of more runs than this take the distribution sort in the 1024-thread shape
 #endif
 template <int THREADS, int CAP, int RUNS>
 struct PsbShape {
@@ -3524,6 +3596,132 @@ struct PsbShape {
 };
 typedef PsbShape<1024, KMX_PSORT_BLOCK_CAP, 128> PsbBig;
 typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
+
+// distribute_sort_lds — the std::sort of kmer_index_result.hpp:258 for a chunk whose positions are SPREAD over the text (the
+// buckets of all k-mers with one prefix are: a k-mer family occurs all over a text without long repeats), as a distribution
+// sort instead of ceil(log2 runs) merge rounds: a position's value bucket is (position * NB) / n — monotone in the position —
+// so (1) every thread counts its positions into the NB buckets (LDS atomics that return the slot inside the bucket), (2) a scan
+// of the counts gives every bucket its place, (3) the positions are scattered to place + slot, (4) every bucket — three or four
+// positions on average — is put in order from registers by an 8-input sorting network (insertion in LDS for the rare longer
+// one), (5) the chunk leaves coalesced.  About half the LDS traffic of four merge rounds, five barriers instead of twelve, and
+// no chain of dependent LDS reads.  Returns false — nothing written but the counters — when some bucket holds more than
+// KMX_PBK_GIVE_UP positions (a repeat of the text: the caller merges instead).
+// out: CAP words, cnt: NB / 2 words (two 16-bit counters per word), wsum: THREADS / 64 + 2 words.
+#define KMX_PBK_NB 8192
+#define KMX_PBK_GIVE_UP 48
+template <int THREADS, int CAP>
+__device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wsum,
+                                                    const uint32_t* __restrict__ seg, uint32_t c_len, uint64_t n_text, uint32_t tid)
+{
+    constexpr int E = CAP / THREADS;                              // positions per thread
+    constexpr int BPT = KMX_PBK_NB / THREADS;                     // buckets per thread in the scan and the bucket sorts
+    static_assert(CAP % THREADS == 0 && KMX_PBK_NB % THREADS == 0 && BPT % 2 == 0 && BPT <= 8, "two counters per word, a thread's counters in one 16-byte read");
+    static_assert(CAP <= 65535 && KMX_PBK_NB <= (1 << 13), "16-bit counters; bucket and slot share a word");
+    const uint32_t mul = uint32_t((uint64_t(KMX_PBK_NB) << 32) / n_text);     // floor: (p * mul) >> 32 < NB for every p < n
+    for (uint32_t i = tid; i < KMX_PBK_NB / 2; i += THREADS) cnt[i] = 0;
+    if (tid == 0) wsum[THREADS / 64] = 0;                         // the longest bucket
+    __syncthreads();
+    // 1. count; the slot inside its bucket is all a position keeps (16 bits: two per register — the position itself is read
+    //    again for the scatter, out of L2, and its bucket recomputed: registers are what this shape is short of)
+    uint32_t slots[E / 2];
+    static_assert(E % 2 == 0, "two slots per register");
+#pragma unroll
+    for (int j2 = 0; j2 < E / 2; ++j2) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t i = uint32_t(2 * j2 + h) * THREADS + tid;
+            uint32_t old = 0, sh = 0;
+            if (i < c_len) {
+                const uint32_t b = __umulhi(seg[i], mul);
+                sh = 16u * (b & 1u);
+                old = atomicAdd(&cnt[b >> 1], 1u << sh);
+            }
+            packed |= ((old >> sh) & 0xFFFFu) << (16 * h);
+        }
+        slots[j2] = packed;
+    }
+    __syncthreads();
+    // 2. exclusive scan of the counts: thread t owns buckets [BPT t, BPT t + BPT)
+    uint32_t c[BPT], st[BPT];
+    {
+        const uint32_t* mine = cnt + tid * (BPT / 2);
+        uint32_t total = 0, longest = 0;
+#pragma unroll
+        for (int u = 0; u < BPT / 2; ++u) {
+            const uint32_t w = mine[u];
+            c[2 * u] = w & 0xFFFFu; c[2 * u + 1] = w >> 16;
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { st[u] = total; total += c[u]; longest = max(longest, c[u]); }
+        uint32_t inc = total;
+        const uint32_t lane = tid & 63u, wv = tid / 64u;
+#pragma unroll
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+            longest = max(longest, uint32_t(__shfl_xor(int(longest), int(o))));
+        }
+        if (lane == 63) wsum[wv] = inc;
+        if (lane == 0 && longest > KMX_PBK_GIVE_UP) atomicMax(&wsum[THREADS / 64], longest);
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w2 = 0; w2 < wv; ++w2) carry += wsum[w2];
+        const bool give_up = wsum[THREADS / 64] != 0;
+        __syncthreads();                                          // (wsum is read: the counters may be overwritten by the places)
+        if (give_up) return false;
+        const uint32_t base = carry + inc - total;
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) st[u] += base;
+        uint32_t* mine_w = cnt + tid * (BPT / 2);
+#pragma unroll
+        for (int u = 0; u < BPT / 2; ++u) mine_w[u] = st[2 * u] | (st[2 * u + 1] << 16);      // places < CAP <= 65535
+    }
+    __syncthreads();
+    // 3. scatter
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t i = uint32_t(j) * THREADS + tid;
+        if (i < c_len) {
+            const uint32_t p = seg[i];
+            const uint32_t b = __umulhi(p, mul), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const uint32_t place = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
+            out[place + slot] = p;
+        }
+    }
+    __syncthreads();
+    // 4. every bucket in order (a thread's BPT buckets are its own: no barrier between them)
+#pragma unroll 1
+    for (int u = 0; u < BPT; ++u) {
+        const uint32_t n_b = c[u];
+        uint32_t* __restrict__ bk = out + st[u];
+        if (n_b >= 2 && n_b <= 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t) v[t] = t < n_b ? bk[t] : 0xFFFFFFFFu;
+            auto cx = [&](int a, int b2) { const uint32_t lo = min(v[a], v[b2]), hi = max(v[a], v[b2]); v[a] = lo; v[b2] = hi; };
+            cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
+            cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
+            cx(1, 2); cx(5, 6); cx(0, 4); cx(3, 7);
+            cx(1, 5); cx(2, 6);
+            cx(1, 4); cx(3, 6);
+            cx(2, 4); cx(3, 5);
+            cx(3, 4);
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t)
+                if (t < n_b) bk[t] = v[t];
+        } else if (n_b > 8) {
+            for (uint32_t i = 1; i < n_b; ++i) {                 // (rare: insertion where it lies)
+                const uint32_t key = bk[i];
+                uint32_t j = i;
+                while (j > 0 && bk[j - 1] > key) { bk[j] = bk[j - 1]; --j; }
+                bk[j] = key;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
 
 template <int THREADS, int CAP, int RUNS, bool MID>
 __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
@@ -3564,6 +3762,16 @@ __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev
             }
             __syncthreads();
             const uint32_t r0 = __builtin_amdgcn_readfirstlane(runs[0]), Rc = __builtin_amdgcn_readfirstlane(runs[1]);
+            if constexpr (!MID) if (Rc > KMX_PBK_MIN_RUNS) {
+                // many runs of positions spread over the text: the distribution sort (it gives up on a repeat of the text)
+                __shared__ uint32_t wsum[THREADS / 64 + 2];
+                if (distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, seg, c_len, ix->n, tid)) {
+                    uint32_t* __restrict__ dst = sorted + c_lo;
+                    for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
+                    __syncthreads();
+                    continue;
+                }
+            }
             const bool merge = Rc <= RUNS;
             if (merge && tid <= Rc) {
                 const uint32_t o = offs[r0 + tid] - offs0;
@@ -3600,7 +3808,7 @@ void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64
     }
     if (n_prefix > n_mid) {
         auto fn = k_prefix_sort_block<1024, KMX_PSORT_BLOCK_CAP, 128, false>;
-        const size_t lds = size_t(PsbBig::WORDS) * 4;
+        const size_t lds = size_t(PsbBig::WORDS + KMX_PBK_NB / 2) * 4;        // (+ the counters of the distribution sort)
         allow_big_lds(reinterpret_cast<const void*>(fn), lds, 0);
         const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
         const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks

@@ -768,6 +768,29 @@ def test_prefix_slices_of_one_long_run_and_of_lopsided_runs(engine, orc):
         idx.close()
 
 
+def test_prefix_slices_whose_positions_cluster_fall_back_to_the_merge(engine, orc):
+    """The distribution sort of the big sub-k slices (distribute_sort_lds) assumes positions spread over the text; a slice whose
+    positions crowd into few value buckets — a long homopolymer, a periodic region — sorts the crowded buckets by insertion and,
+    past KMX_PBK_GIVE_UP positions in one bucket, gives the chunk to the merge rounds.  Same lists either way."""
+    rng = np.random.default_rng(11)
+    text = rng.integers(0, 4, 700_000).astype(np.uint8)
+    text[100_000:220_000] = 0                                           # 120 000 x 'A': consecutive positions in ONE run
+    text[400_000:460_000] = np.tile(np.array([0, 1, 0, 2, 0, 3, 0, 0], np.uint8), 7_500)    # period 8: every 8th position, several runs
+    for ks in ([6], [8]):
+        idx = engine.Index(text, 4, ks, prefix_levels=-1)
+        oidx = orc.Index(text, 4, ks)
+        qs = [np.array(q, np.uint8) for q in ([0], [0, 0], [0, 0, 0], [0, 1], [0, 1, 0], [1, 0, 2], [0, 0, 0, 0], [3], [2, 0], [0, 3, 0, 0])]
+        qs += [text[s0:s0 + m].copy() for m in (1, 2, 3, 4) for s0 in (5, 150_000, 410_003, 650_000)]
+        qranks, qoff = pack(qs)
+        idx.stats_enable(True)
+        ho, pos, st, kd = idx.search(qranks, qoff).host()
+        o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+        assert (kd == engine.KIND_PREFIX).all()
+        assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), ks
+        assert idx.stats()["k_prefix_sort_block"]["launches"]
+        idx.close()
+
+
 @pytest.mark.parametrize("sigma,ks", [(4, [16]), (4, [14, 20, 31]), (2, [40, 63]), (20, [7, 12]), (5, [12, 4])])
 def test_sorted_pairs_device_build_equals_host_flatten(engine, orc, sigma, ks, tmp_path):
     """Elements whose key space is beyond the histogram path (sigma^k > 2^26) are built on the device from sorted
