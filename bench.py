@@ -237,11 +237,11 @@ def worker(args):
     # ------------------------------------------------------------------------------------------------------------
     sh_streams = [main_stream] + [torch.cuda.Stream(device=dev) for _ in range(max(depth, 2) - 1)]
 
-    def run_sharded(index, steps, warmup, collect_stats, n_streams=1, queries=None):
+    def run_sharded(index, steps, warmup, collect_stats, n_streams=1, queries=None, extra_flags=0):
         d_qr, d_qoff, nq = queries or main_queries
         n_streams = max(1, min(n_streams, depth))
         results = [engine.Result() for _ in range(depth)]
-        flags = engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT
+        flags = (engine.SEARCH_ASYNC if depth > 1 else engine.SEARCH_DEFAULT) | extra_flags
         no = [0]
 
         def step():
@@ -253,7 +253,7 @@ def worker(args):
         # batch) before the W warmup steps, so that neither warmup nor the timed region holds an allocation
         for h, r_ in enumerate(results):
             for _ in range(2):
-                index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, stream=sh_streams[h % n_streams].cuda_stream, result=r_)
+                index.search_device(d_qr.data_ptr(), d_qoff.data_ptr(), nq, flags=extra_flags, stream=sh_streams[h % n_streams].cuda_stream, result=r_)
         torch.cuda.synchronize()
         for _ in range(warmup):
             step()
@@ -461,6 +461,17 @@ def worker(args):
                                 "same_hit_total": bool(res2c[0].counts()["n_hits"] == cn["n_hits"])}
             for r_ in res2c:
                 r_.close()
+        if cfg == 3:
+            # the same steps on the REFERENCE's planner table (KMX_SEARCH_REFERENCE_PLAN): sums of two different ks stitched as the
+            # reference stitches them (kmer_index.hpp:515-557) — the default answers those lengths from the largest k
+            el_r, res_r, st_r = run_sharded(idx_c, args.steps, args.warmup, True, 1, q_c, engine.SEARCH_REFERENCE_PLAN)
+            o["reference_plan"] = {"value": round(nq_c * args.steps / el_r / 1e6, 3), "ms_per_step": round(el_r / args.steps * 1e3, 4),
+                                   "job_frac": round(job_b / (el_r / args.steps) / 1e9 / HBM_PEAK_GBPS, 4),
+                                   "same_hit_total": bool(res_r[0].counts()["n_hits"] == cn["n_hits"]),
+                                   "kernels_avg_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st_r.items() if v["launches"]},
+                                   "what": "KMX_SEARCH_REFERENCE_PLAN: every query on the element(s) the reference's planner names (multi-k sums as sums)"}
+            for r_ in res_r:
+                r_.close()
         if cfg == 3:                                                   # sub-k queries and short reads on the multi-k index
             o["length_probes"] = {f"m={m_}": length_probe(idx_c, text_c, sg, m_, nq_p) for m_, nq_p in ((6, 50_000), (7, 200_000), (13, 500_000), (16, 500_000))}
         idx_c.close()
@@ -508,6 +519,17 @@ def worker(args):
                 "ranks_seen": int(dist.get_world_size()), "all_reduce_ok": int(chk.item()) == world * (world + 1) // 2,
                 "devices_visible": n_dev}
     elapsed = float(t_el[0].item())
+
+    # ---- config 3 alone (`--config 3`): the same steps on the reference's planner table (multi-k sums stitched as sums) ----
+    ref_plan_leg = None
+    if world == 1 and args.config == 3 and not args.no_open_compare:
+        el_r, res_r, st_r = run_sharded(idx, args.steps, args.warmup, True, 1, None, engine.SEARCH_REFERENCE_PLAN)
+        ref_plan_leg = {"value": round(nq * args.steps / el_r / 1e6, 3), "ms_per_step": round(el_r / args.steps * 1e3, 4),
+                        "same_hit_total": bool(res_r[0].counts()["n_hits"] == counts["n_hits"]),
+                        "kernels_avg_ms": {k: round(v["total_ms"] / max(v["launches"], 1), 4) for k, v in st_r.items() if v["launches"]},
+                        "what": "KMX_SEARCH_REFERENCE_PLAN: every query on the element(s) the reference's planner names (multi-k sums as sums, kmer_index.hpp:515-557)"}
+        for r_ in res_r:
+            r_.close()
 
     # ---- the literal north_star variant (open-addressing probe) on the same workload and the same pipeline, outside the timed region ----
     open_leg = None
@@ -716,6 +738,7 @@ def worker(args):
             "gather_hits": None,
             "two_streams": two_streams,
             "open_addressing_table": open_leg,
+            "reference_plan": ref_plan_leg,
             "cpu_baseline": cpu_baseline,
             "host_api": host_api,
             "length_probes": length_probes,

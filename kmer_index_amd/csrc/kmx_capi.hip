@@ -246,6 +246,7 @@ struct kmx_result {
     bool small_valid = false;              // the result of the last search lives in the mailbox only (no device buffers were written)
     bool host_valid = false, host_masks_valid = false;
     bool last_had_stitch = false;          // adaptive speculation: see kmx_search_batch_device
+    bool last_had_long = false;            // ... or queries of very many parts (k_lookup_long)
     bool last_had_pairs = false;           // the previous batch held cross-referenced queries: k_lookup's variant (kmx_search_batch_device)
     std::shared_ptr<ResultPool> pool;      // where kmx_result_free parks this result (set by the search that made it)
     SearchCtx ctx;                         // the half-done search of a KMX_SEARCH_ASYNC call (search_finish completes it)
@@ -1495,7 +1496,14 @@ kmx_status kmx_search_batch_device(const kmx_index* cix, const void* d_qranks, c
     static const int force_items = getenv("KMX_LOOKUP_ITEMS") ? atoi(getenv("KMX_LOOKUP_ITEMS")) : 0;      // (tuning / tests: 4 | 8, or -4: 4 with pairs)
     const bool pairs = force_items ? force_items == -4 : r->last_had_pairs;
     const int items = force_items ? (force_items == 8 ? 8 : 4) : (!pairs && ix->tiny_cells) ? 8 : 4;
-    timed(ix, K_LOOKUP, s, [&] { kmx::launch_lookup(s, items, pairs, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), flags); });
+    // ... and queries of very many parts (5000-letter reads): when the batch before held some, k_lookup only lists them and
+    // k_lookup_long gives each a wave (a lane per part) before the scan reads the counters
+    const bool defer_long = r->last_had_long;
+    const uint32_t lflags = (flags & ~KMX_SEARCH_INTERNAL_DEFER_LONG) | (defer_long ? KMX_SEARCH_INTERNAL_DEFER_LONG : 0u);
+    timed(ix, K_LOOKUP, s, [&] {
+        kmx::launch_lookup(s, items, pairs, dix, qr, qo, nq, d, ctr, r->bsum.as<uint64_t>(), lflags);
+        if (defer_long) kmx::launch_lookup_long(s, dix, qr, qo, nq, d, ctr, flags);
+    });
     // speculative scan: already final when the batch holds no STITCH query
     // The downsweep also records the first query of every output tile (k_partition's job) when the
     // tile table kept from an earlier batch is large enough — the steady state.
@@ -1577,6 +1585,7 @@ static kmx_status search_finish(kmx_result* r)
     const uint64_t n_stitch_pending = n_stitch_groups + n_stitch_tiny + n_stitch_short;                 // still to be validated
     r->n_stitch = n_stitch_pending + r->h_ctr[KMX_CTR_STITCH_RESOLVED];                                  // (k_lookup resolved the others itself)
     r->last_had_stitch = n_stitch_pending != 0;
+    r->last_had_long = r->h_ctr[KMX_CTR_LONG] != 0;
     r->last_had_pairs = r->n_stitch != 0;                        // (resolved ones included: they are what the pairs variant of k_lookup is for)
     const uint64_t n_prefix_small = r->h_ctr[KMX_CTR_PREFIX], n_prefix_big = r->h_ctr[KMX_CTR_PREFIX_BIG];
     r->n_prefix = n_prefix_small + n_prefix_big + r->h_ctr[KMX_CTR_PREFIX_PLAIN];
@@ -1763,6 +1772,7 @@ static kmx_status search_host_one(kmx_index* ix, const uint8_t* qranks, const ui
             r->quiesced = true;
             r->last_had_stitch = false;
             r->last_had_pairs = false;
+            r->last_had_long = false;
             r->pool = ix->pool;                                 // (kmx_result_view_device asks it whether the index is still there)
             return KMX_OK;
         }

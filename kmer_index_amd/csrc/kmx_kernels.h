@@ -29,6 +29,9 @@ struct QueryDesc {
 uint64_t lookup_blocks(uint64_t nq, int items);
 void launch_lookup(hipStream_t s, int items, bool pairs, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff,
                    uint64_t nq, const QueryDesc& d, unsigned long long* ctr, uint64_t* block_hits, uint32_t flags);
+// behind launch_lookup with KMX_SEARCH_INTERNAL_DEFER_LONG in its flags: the queries of very many parts it listed, a wave each
+void launch_lookup_long(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq, const QueryDesc& d,
+                        unsigned long long* ctr, uint32_t flags);
 void launch_validate(hipStream_t s, const KmxIndexDev* ix, const uint32_t* arena, const uint8_t* qranks, const uint64_t* qoff,
                      const QueryDesc& d, uint64_t n_stitch, uint64_t n_more, uint64_t n_tiny, const uint32_t* tiny_list, uint64_t n_short,
                      uint64_t* mask_words, bool direct);   // direct: tiny queries whose survivors are one run of the first bucket leave as plain copies

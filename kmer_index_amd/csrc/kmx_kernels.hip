@@ -498,6 +498,7 @@ __device__ __forceinline__ void lookup_query(const KmxIndexDev* __restrict__ ix,
 // k_lookup — one query per lane.
 // ---------------------------------------------------------------------------
 struct BlockCounters {
+    unsigned int n_long, base_long;
     unsigned int n_stitch, n_stitch_tiny, n_stitch_short, n_resolved, n_prefix, n_prefix_big, n_prefix_merge, n_prefix_mid, n_prefix_plain, n_error, n_none, n_more;
     unsigned long long words, pelems, hits;
     unsigned int max_runs;
@@ -525,13 +526,13 @@ __device__ __forceinline__ bool hash16(const u32x4_a1& w, uint32_t len, uint32_t
         lo = sh >= 64u ? 0 : lo1;
     }
     const uint32_t wd[4] = {uint32_t(lo), uint32_t(lo >> 32), uint32_t(hi), uint32_t(hi >> 32)};
-    bool ok = true;
+    uint32_t top = 0;                                                 // the largest rank met: one compare at the end
     if (SMALL) {
         uint32_t acc = 0;
 #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t r = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            ok &= r < sigma;
+            top = max(top, r);
             acc = __umul24(acc, sigma) + r;
         }
         h = acc;
@@ -540,12 +541,12 @@ __device__ __forceinline__ bool hash16(const u32x4_a1& w, uint32_t len, uint32_t
 #pragma unroll
         for (uint32_t j = 0; j < 16; ++j) {
             const uint32_t r = (wd[j >> 2] >> (8 * (j & 3))) & 0xFFu;
-            ok &= r < sigma;
+            top = max(top, r);
             acc = acc * sigma + r;
         }
         h = acc;
     }
-    return ok;
+    return top < sigma;
 }
 // at(hash) (kmer_index.hpp:76-84) in two halves, so that the loads of several queries can be in flight together:
 // where the first 16 bytes of the probe lie — dense: the table entries of h (cnt8 / atab / offs); open: the home slot —
@@ -613,6 +614,7 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
     __shared__ uint32_t plan_s[KMX_PLAN_LDS];       // the planner's entries of the short lengths (second summand of a multi-k pair)
     static_assert(KMX_PLAN_LDS == KMX_BLOCK, "one planner entry per thread");
     if (threadIdx.x == 0) {
+        bc.n_long = 0;
         bc.n_stitch = bc.n_stitch_tiny = bc.n_stitch_short = bc.n_resolved = bc.n_prefix = bc.n_prefix_big = bc.n_prefix_merge = bc.n_prefix_mid = bc.n_prefix_plain = bc.n_error = bc.n_none = bc.n_more = 0;
         bc.words = bc.pelems = bc.hits = 0;
         bc.max_runs = 0;
@@ -859,15 +861,21 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
                 const uint32_t lv[16] = {P.l0.x, P.l0.y, P.l0.z, P.l0.w, P.l1.x, P.l1.y, P.l1.z, P.l1.w, P.l2.x, P.l2.y, P.l2.z, P.l2.w, P.l3.x, P.l3.y, P.l3.z, P.l3.w};
                 const uint32_t n_s = P.first_is_short ? P.c0 : P.pc, n_l = P.first_is_short ? P.pc : P.c0;
                 const uint32_t shift = P.first_is_short ? P.off : 0u - P.off;
+                // (entries past a list's end never match: L's read 0xFFFFFFFF, S's look for 0xFFFFFFFE — neither is a position, a wrapped
+                //  s - off is sent to 0xFFFFFFFE too; membership as the minimum of x ^ l over L: vector instructions only)
+                uint32_t lm[16];
+#pragma unroll
+                for (uint32_t b = 0; b < 16; ++b) lm[b] = b < n_l ? lv[b] : 0xFFFFFFFFu;
                 uint32_t met = 0;                                  // bit a: S[a] is met in L (binary_search :283, lower_bound :544-546)
                 uint32_t last = 0;                                 // the last such entry, as a start position's partner in L
 #pragma unroll
                 for (uint32_t a = 0; a < 8; ++a) {
-                    const uint32_t x = sv[a] + shift;
-                    bool hit = false;
+                    const bool usable = a < n_s && (P.first_is_short || sv[a] >= P.off);
+                    const uint32_t x = usable ? sv[a] + shift : 0xFFFFFFFEu;
+                    uint32_t diff = 0xFFFFFFFFu;
 #pragma unroll
-                    for (uint32_t b = 0; b < 16; ++b) hit |= b < n_l && x == lv[b];
-                    hit = hit && a < n_s;
+                    for (uint32_t b = 0; b < 16; b += 2) diff = min(diff, min(x ^ lm[b], x ^ lm[b + 1]));
+                    const bool hit = diff == 0;
                     met |= uint32_t(hit) << a;
                     last = hit ? x : last;
                 }
@@ -881,7 +889,7 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
                     // the walked list was the SECOND part's: the one survivor's place in the first bucket (= L) is its rank there
                     uint32_t rank = 0;
 #pragma unroll
-                    for (uint32_t b = 0; b < 16; ++b) rank += uint32_t(b < n_l && lv[b] < last);
+                    for (uint32_t b = 0; b < 16; ++b) rank += uint32_t(lm[b] < last);
                     resolved = true; src = P.src + (n_met ? rank : 0u); cnt = n_met;
                 }
             }
@@ -913,8 +921,25 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
         if (q >= nq) continue;
         const uint64_t b = qoff[q];
         const uint64_t m = qoff[q + 1] - b;
+        // A query of very many parts (a 5000-letter read on k = 10: 500 probes) walked by ONE lane is a chain of hundreds of
+        // dependent round trips; such queries are counted, and — when the engine has launched k_lookup_long behind this kernel
+        // (it does when the batch before held some) — only listed here: there a wave takes the query, a lane per part.
+        if (m > 0 && m < range) {
+            const KmxPlanEntry pe = plan_unpack(plan_effective(m < KMX_PLAN_LDS ? plan_s[m] : ((const KMX_GLOBAL uint32_t*)ix->plan)[m]));
+            if (pe.scheme == KMX_SCHEME_SINGLE) {
+                const uint32_t k = elems_s[pe.elem].k;
+                if (m > uint64_t(k) * KMX_LONG_PARTS) {
+                    const unsigned int slot = atomicAdd(&bc.n_long, 1u);
+                    if (flags & KMX_SEARCH_INTERNAL_DEFER_LONG) {
+                        kinds[it] = 0xFF;                        // (listed in the last phase, from the back of short_list)
+                        locs[it] = slot;
+                        continue;
+                    }
+                }
+            }
+        }
         LookupOut lo;
-        lookup_query(ix, elems_s, qranks + b, m, qend, flags, lo);
+        lookup_query(ix, elems_s, qranks + b, m, qend, flags & ~KMX_SEARCH_INTERNAL_DEFER_LONG, lo);
         emit(it, q, lo.kind, lo.status, lo.src, lo.aux, lo.key, lo.p1, lo.cnt, lo.c0, lo.resolved);
     }
 
@@ -942,6 +967,7 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
             if (bc.pelems) atomicAdd(&ctr[KMX_CTR_PREFIX_ELEMS], bc.pelems);
             if (bc.max_runs) atomicMax(&ctr[KMX_CTR_MAX_RUNS], (unsigned long long)bc.max_runs);
         }
+        if (bc.n_long) bc.base_long = (unsigned int)atomicAdd(&ctr[KMX_CTR_LONG], (unsigned long long)bc.n_long);
         if (bc.n_resolved) atomicAdd(&ctr[KMX_CTR_STITCH_RESOLVED], (unsigned long long)bc.n_resolved);
         if (bc.n_error) atomicAdd(&ctr[KMX_CTR_ERROR], (unsigned long long)bc.n_error);
         if (bc.n_none) atomicAdd(&ctr[KMX_CTR_NONE], (unsigned long long)bc.n_none);
@@ -950,7 +976,9 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint64_t q = (uint64_t(blockIdx.x) * ITEMS + it) * KMX_BLOCK + threadIdx.x;
-        if (kinds[it] == KMX_KIND_STITCH) {
+        if (kinds[it] == 0xFF) {
+            d.short_list[nq - 1 - (bc.base_long + locs[it])] = uint32_t(q);      // deferred to k_lookup_long
+        } else if (kinds[it] == KMX_KIND_STITCH) {
             d.aux[q] = bc.base_words + locw[it];              // first mask word of this query
             if (locs[it] & 0x80000000u) d.stitch_list[nq - 1 - (bc.base_stitch_tiny + (locs[it] & 0x3FFFFFFFu))] = uint32_t(q);
             else if (locs[it] & 0x40000000u) d.short_list[bc.base_stitch_short + (locs[it] & 0x3FFFFFFFu)] = uint32_t(q);
@@ -960,6 +988,92 @@ __global__ __launch_bounds__(KMX_BLOCK, PAIRS ? KMX_LOOKUP_OCC : (ITEMS > 4 ? 4 
             else d.prefix_list[bc.base_prefix + locs[it]] = uint32_t(q);
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// k_lookup_long — single-k queries of more than KMX_LONG_PARTS parts that k_lookup listed instead of walking (:207-339 with
+// hundreds of parts): one WAVE per query, a lane per part — rank-hash and probe of all parts in parallel (64 at a time), then
+// the outcome of the reference's walk: it looks at the parts in order and stops at the first one that is missing (:221-224:
+// an empty result) — a letter outside the alphabet only counts in a part it reaches — and throws for a rest whose prefix range
+// is too wide (:119-122 via :234) only when every full part was found.  Lane 0 writes the descriptor and does the work-list
+// bookkeeping of k_lookup's emit() with global atomics (these queries are few).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(KMX_BLOCK) void k_lookup_long(const KmxIndexDev* __restrict__ ix, const uint8_t* __restrict__ qranks,
+                                                           const uint64_t* __restrict__ qoff, uint64_t nq, QueryDesc d,
+                                                           unsigned long long* __restrict__ ctr, uint32_t flags)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    const uint64_t n_long = ctr[KMX_CTR_LONG];
+    const uint8_t* __restrict__ qend = qranks + qoff[nq];
+    const uint32_t sigma = ix->sigma;
+    for (uint64_t i = wave; i < n_long; i += n_waves) {
+        const uint32_t q = d.short_list[nq - 1 - i];
+        const uint64_t b = qoff[q], m = qoff[q + 1] - b;
+        const uint8_t* __restrict__ qr = qranks + b;
+        const KmxPlanEntry pe = load_plan(ix, m);
+        const KmxElemDev* __restrict__ el = &ix->elems[pe.elem];
+        const uint32_t k = el->k;
+        const uint32_t P = uint32_t(m / k), rest = uint32_t(m % k);
+        const bool fan = rest && ix->pw[k - rest] > KMX_SUBK_FANOUT_LIMIT;
+        const uint32_t n_parts = P + ((rest && !fan) ? 1u : 0u);                      // (the rest is only looked at when its lookup would not throw)
+        uint32_t my_stop = 0xFFFFFFFFu;                                              // first part of this lane at which the walk would stop, x 2 + (1: missing, 0: bad letter)
+        Run first{0, 0}, last{0, 0};
+        for (uint32_t j = lane; j < n_parts; j += KMX_WAVE) {
+            const uint64_t start = j < P ? uint64_t(j) * k : m - k;
+            uint64_t h;
+            const bool ok = rank_hash(qr + start, k, sigma, h, qend);
+            Run r{0, 0};
+            if (ok) r = probe(el, h);
+            if ((!ok || r.cnt == 0) && my_stop == 0xFFFFFFFFu) my_stop = 2 * j + (ok ? 1u : 0u);
+            if (j == 0) first = r;
+            if (j == n_parts - 1) last = r;
+        }
+        uint32_t stop = my_stop;
+        for (int off = 32; off > 0; off >>= 1) stop = min(stop, uint32_t(__shfl_xor(int(stop), off)));
+        const int last_lane = int((n_parts - 1) % KMX_WAVE);
+        const uint64_t last_src = __shfl(last.src, last_lane);
+        const uint32_t last_cnt = uint32_t(__shfl(int(last.cnt), last_lane));
+        if (lane != 0) continue;
+        uint8_t kind = KMX_KIND_NONE, status = KMX_Q_OK;
+        if (stop != 0xFFFFFFFFu) {
+            if (!(stop & 1u)) status = KMX_Q_BAD_RANK;
+        } else if (fan) {
+            status = KMX_Q_SUBK_FANOUT;
+        } else {
+            kind = KMX_KIND_STITCH;
+        }
+        d.cnt[q] = 0;
+        d.kind[q] = kind;
+        d.status[q] = status;
+        if (kind != KMX_KIND_STITCH) {
+            d.src[q] = 0;
+            atomicAdd(&ctr[status != KMX_Q_OK ? KMX_CTR_ERROR : KMX_CTR_NONE], 1ull);
+            continue;
+        }
+        const uint32_t c0 = first.cnt, delta = uint32_t(rest ? m - k : uint64_t(P - 1) * k);
+        uint64_t p1 = (uint64_t(delta) << 32) | last_cnt | KMX_P1_MORE;                // (more than KMX_LONG_PARTS parts: always further ones)
+        if (!(flags & KMX_SEARCH_KEEP_MASKS) && stitch_goes_big(c0, last_cnt)) p1 |= KMX_P1_BIG;
+        d.src[q] = first.src | SRC_SLOW;
+        d.c0[q] = c0;
+        d.key[q] = last_src;
+        d.p1[q] = p1;
+        d.aux[q] = atomicAdd(&ctr[KMX_CTR_MASK_WORDS], (unsigned long long)(uint64_t(c0) / 64 + 1));     // compressed_bitset.hpp:23
+        if (min(c0, last_cnt) <= KMX_VTINY && max(c0, last_cnt) <= 2 * KMX_VTINY) {
+            d.stitch_list[nq - 1 - atomicAdd(&ctr[KMX_CTR_STITCH_TINY], 1ull)] = q;
+        } else {
+            atomicAdd(&ctr[KMX_CTR_STITCH_MORE], 1ull);
+            d.stitch_list[atomicAdd(&ctr[KMX_CTR_STITCH], 1ull)] = q;
+        }
+    }
+}
+
+void launch_lookup_long(hipStream_t s, const KmxIndexDev* ix, const uint8_t* qranks, const uint64_t* qoff, uint64_t nq, const QueryDesc& d,
+                        unsigned long long* ctr, uint32_t flags)
+{
+    // (the number of listed queries is on the device: a fixed grid, every wave strides over the list)
+    hipLaunchKernelGGL(k_lookup_long, dim3(256 * 4), dim3(KMX_BLOCK), 0, s, ix, qranks, qoff, nq, d, ctr, flags);
 }
 
 // ---------------------------------------------------------------------------
@@ -3583,9 +3697,6 @@ void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uin
 #ifndef KMX_PSB_CPT
 #define KMX_PSB_CPT 1          // chunks per thread and round in k_prefix_sort_block (merge_chunks: chains in lockstep; 2 measured slower:
 #endif                         // the merge-path searches double and the LDS pipe, not its latency, is what the rounds wait for)
-#ifndef KMX_PBK_MIN_RUNS
-#define KMX_PBK_MIN_RUNS 4     // chunks of more runs than this take the distribution sort in the 1024-thread shape
-#endif
 template <int THREADS, int CAP, int RUNS>
 struct PsbShape {
     static constexpr int CPT = KMX_PSB_CPT;
@@ -3596,132 +3707,6 @@ struct PsbShape {
 };
 typedef PsbShape<1024, KMX_PSORT_BLOCK_CAP, 128> PsbBig;
 typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
-
-// distribute_sort_lds — the std::sort of kmer_index_result.hpp:258 for a chunk whose positions are SPREAD over the text (the
-// buckets of all k-mers with one prefix are: a k-mer family occurs all over a text without long repeats), as a distribution
-// sort instead of ceil(log2 runs) merge rounds: a position's value bucket is (position * NB) / n — monotone in the position —
-// so (1) every thread counts its positions into the NB buckets (LDS atomics that return the slot inside the bucket), (2) a scan
-// of the counts gives every bucket its place, (3) the positions are scattered to place + slot, (4) every bucket — three or four
-// positions on average — is put in order from registers by an 8-input sorting network (insertion in LDS for the rare longer
-// one), (5) the chunk leaves coalesced.  About half the LDS traffic of four merge rounds, five barriers instead of twelve, and
-// no chain of dependent LDS reads.  Returns false — nothing written but the counters — when some bucket holds more than
-// KMX_PBK_GIVE_UP positions (a repeat of the text: the caller merges instead).
-// out: CAP words, cnt: NB / 2 words (two 16-bit counters per word), wsum: THREADS / 64 + 2 words.
-#define KMX_PBK_NB 8192
-#define KMX_PBK_GIVE_UP 48
-template <int THREADS, int CAP>
-__device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wsum,
-                                                    const uint32_t* __restrict__ seg, uint32_t c_len, uint64_t n_text, uint32_t tid)
-{
-    constexpr int E = CAP / THREADS;                              // positions per thread
-    constexpr int BPT = KMX_PBK_NB / THREADS;                     // buckets per thread in the scan and the bucket sorts
-    static_assert(CAP % THREADS == 0 && KMX_PBK_NB % THREADS == 0 && BPT % 2 == 0 && BPT <= 8, "two counters per word, a thread's counters in one 16-byte read");
-    static_assert(CAP <= 65535 && KMX_PBK_NB <= (1 << 13), "16-bit counters; bucket and slot share a word");
-    const uint32_t mul = uint32_t((uint64_t(KMX_PBK_NB) << 32) / n_text);     // floor: (p * mul) >> 32 < NB for every p < n
-    for (uint32_t i = tid; i < KMX_PBK_NB / 2; i += THREADS) cnt[i] = 0;
-    if (tid == 0) wsum[THREADS / 64] = 0;                         // the longest bucket
-    __syncthreads();
-    // 1. count; the slot inside its bucket is all a position keeps (16 bits: two per register — the position itself is read
-    //    again for the scatter, out of L2, and its bucket recomputed: registers are what this shape is short of)
-    uint32_t slots[E / 2];
-    static_assert(E % 2 == 0, "two slots per register");
-#pragma unroll
-    for (int j2 = 0; j2 < E / 2; ++j2) {
-        uint32_t packed = 0;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t i = uint32_t(2 * j2 + h) * THREADS + tid;
-            uint32_t old = 0, sh = 0;
-            if (i < c_len) {
-                const uint32_t b = __umulhi(seg[i], mul);
-                sh = 16u * (b & 1u);
-                old = atomicAdd(&cnt[b >> 1], 1u << sh);
-            }
-            packed |= ((old >> sh) & 0xFFFFu) << (16 * h);
-        }
-        slots[j2] = packed;
-    }
-    __syncthreads();
-    // 2. exclusive scan of the counts: thread t owns buckets [BPT t, BPT t + BPT)
-    uint32_t c[BPT], st[BPT];
-    {
-        const uint32_t* mine = cnt + tid * (BPT / 2);
-        uint32_t total = 0, longest = 0;
-#pragma unroll
-        for (int u = 0; u < BPT / 2; ++u) {
-            const uint32_t w = mine[u];
-            c[2 * u] = w & 0xFFFFu; c[2 * u + 1] = w >> 16;
-        }
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) { st[u] = total; total += c[u]; longest = max(longest, c[u]); }
-        uint32_t inc = total;
-        const uint32_t lane = tid & 63u, wv = tid / 64u;
-#pragma unroll
-        for (uint32_t o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(inc, o);
-            if (lane >= o) inc += t;
-            longest = max(longest, uint32_t(__shfl_xor(int(longest), int(o))));
-        }
-        if (lane == 63) wsum[wv] = inc;
-        if (lane == 0 && longest > KMX_PBK_GIVE_UP) atomicMax(&wsum[THREADS / 64], longest);
-        __syncthreads();
-        uint32_t carry = 0;
-        for (uint32_t w2 = 0; w2 < wv; ++w2) carry += wsum[w2];
-        const bool give_up = wsum[THREADS / 64] != 0;
-        __syncthreads();                                          // (wsum is read: the counters may be overwritten by the places)
-        if (give_up) return false;
-        const uint32_t base = carry + inc - total;
-#pragma unroll
-        for (int u = 0; u < BPT; ++u) st[u] += base;
-        uint32_t* mine_w = cnt + tid * (BPT / 2);
-#pragma unroll
-        for (int u = 0; u < BPT / 2; ++u) mine_w[u] = st[2 * u] | (st[2 * u + 1] << 16);      // places < CAP <= 65535
-    }
-    __syncthreads();
-    // 3. scatter
-#pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const uint32_t i = uint32_t(j) * THREADS + tid;
-        if (i < c_len) {
-            const uint32_t p = seg[i];
-            const uint32_t b = __umulhi(p, mul), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            const uint32_t place = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
-            out[place + slot] = p;
-        }
-    }
-    __syncthreads();
-    // 4. every bucket in order (a thread's BPT buckets are its own: no barrier between them)
-#pragma unroll 1
-    for (int u = 0; u < BPT; ++u) {
-        const uint32_t n_b = c[u];
-        uint32_t* __restrict__ bk = out + st[u];
-        if (n_b >= 2 && n_b <= 8) {
-            uint32_t v[8];
-#pragma unroll
-            for (uint32_t t = 0; t < 8; ++t) v[t] = t < n_b ? bk[t] : 0xFFFFFFFFu;
-            auto cx = [&](int a, int b2) { const uint32_t lo = min(v[a], v[b2]), hi = max(v[a], v[b2]); v[a] = lo; v[b2] = hi; };
-            cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
-            cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
-            cx(1, 2); cx(5, 6); cx(0, 4); cx(3, 7);
-            cx(1, 5); cx(2, 6);
-            cx(1, 4); cx(3, 6);
-            cx(2, 4); cx(3, 5);
-            cx(3, 4);
-#pragma unroll
-            for (uint32_t t = 0; t < 8; ++t)
-                if (t < n_b) bk[t] = v[t];
-        } else if (n_b > 8) {
-            for (uint32_t i = 1; i < n_b; ++i) {                 // (rare: insertion where it lies)
-                const uint32_t key = bk[i];
-                uint32_t j = i;
-                while (j > 0 && bk[j - 1] > key) { bk[j] = bk[j - 1]; --j; }
-                bk[j] = key;
-            }
-        }
-    }
-    __syncthreads();
-    return true;
-}
 
 template <int THREADS, int CAP, int RUNS, bool MID>
 __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
@@ -3762,16 +3747,6 @@ __global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev
             }
             __syncthreads();
             const uint32_t r0 = __builtin_amdgcn_readfirstlane(runs[0]), Rc = __builtin_amdgcn_readfirstlane(runs[1]);
-            if constexpr (!MID) if (Rc > KMX_PBK_MIN_RUNS) {
-                // many runs of positions spread over the text: the distribution sort (it gives up on a repeat of the text)
-                __shared__ uint32_t wsum[THREADS / 64 + 2];
-                if (distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, seg, c_len, ix->n, tid)) {
-                    uint32_t* __restrict__ dst = sorted + c_lo;
-                    for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
-                    __syncthreads();
-                    continue;
-                }
-            }
             const bool merge = Rc <= RUNS;
             if (merge && tid <= Rc) {
                 const uint32_t o = offs[r0 + tid] - offs0;
@@ -3808,7 +3783,7 @@ void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64
     }
     if (n_prefix > n_mid) {
         auto fn = k_prefix_sort_block<1024, KMX_PSORT_BLOCK_CAP, 128, false>;
-        const size_t lds = size_t(PsbBig::WORDS + KMX_PBK_NB / 2) * 4;        // (+ the counters of the distribution sort)
+        const size_t lds = size_t(PsbBig::WORDS) * 4;
         allow_big_lds(reinterpret_cast<const void*>(fn), lds, 0);
         const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
         const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks

@@ -212,5 +212,10 @@ enum {
     KMX_CTR_PREFIX_MID = 15,   // of KMX_CTR_PREFIX_BIG: slices of at most KMX_PSORT_MID_CAP positions (k_prefix_sort_block's 256-thread variant)
     KMX_CTR_PREFIX_PLAIN = 0,  // PREFIX queries answered by ONE list (nothing to sort: on no work list)
     KMX_CTR_STITCH_SHORT = 16, // two-part STITCH queries whose shorter bucket has at most KMX_VSHORT entries (listed in QueryDesc::short_list)
+    KMX_CTR_LONG = 17,         // single-k queries of more than KMX_LONG_PARTS parts (k_lookup_long takes them when the batch before had some)
     KMX_CTR_COUNT = 20
 };
+#define KMX_LONG_PARTS 256      // parts beyond which a query's probes are spread over the lanes of a wave instead of walked by one lane
+                                // (measured: 100 parts — 1000 letters on k = 10 — are faster walked, 0.76 against 2.5 ms per 1e5 reads: a
+                                //  wave per query pays its serial epilogue per query; 500 parts 0.56 against 3.76 ms per 2e4 reads)
+#define KMX_SEARCH_INTERNAL_DEFER_LONG 0x80000000u   // (k_lookup's flags, set by the engine) such queries are listed for k_lookup_long, not walked

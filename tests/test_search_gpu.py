@@ -768,10 +768,67 @@ def test_prefix_slices_of_one_long_run_and_of_lopsided_runs(engine, orc):
         idx.close()
 
 
-def test_prefix_slices_whose_positions_cluster_fall_back_to_the_merge(engine, orc):
-    """The distribution sort of the big sub-k slices (distribute_sort_lds) assumes positions spread over the text; a slice whose
-    positions crowd into few value buckets — a long homopolymer, a periodic region — sorts the crowded buckets by insertion and,
-    past KMX_PBK_GIVE_UP positions in one bucket, gives the chunk to the merge rounds.  Same lists either way."""
+def test_queries_of_very_many_parts_take_a_wave_each(engine, orc):
+    """Queries of more than KMX_LONG_PARTS (256) parts: walked by one lane in the first batch on a handle, listed by k_lookup and
+    taken by k_lookup_long (a wave per query, a lane per part) from the second batch on — the same statuses, kinds and lists:
+    planted reads, reads with one changed letter (the walk stops at a missing part), a letter outside the alphabet before and
+    behind the first missing part (kmer_index.hpp:216-227: only a part the walk reaches counts), a rest whose prefix range would
+    throw (:119-122 via :234) with and without a missing part in front of it."""
+    rng = np.random.default_rng(5)
+    for sigma, k, n in ((4, 8, 300_000), (4, 13, 300_000), (20, 3, 100_000)):
+        text = synth.ranks(900 + k, n, sigma)
+        qs = []
+        for m in (k * 257, k * 257 + 1, k * 300 + k // 2, k * 320, k * 321 + 1, k * 530 + 2, k * 100):
+            for t in range(6):
+                s0 = int(rng.integers(0, n - m))
+                q = text[s0:s0 + m].copy()
+                if t == 1:
+                    q[int(rng.integers(0, m))] = (int(q[0]) + 1 + int(rng.integers(0, sigma - 1))) % sigma     # some part goes missing (or not)
+                elif t == 2:
+                    q[m // 2] = 250                                                   # a letter outside the alphabet, nothing missing in front of it
+                elif t == 3:
+                    q[5] = (int(q[5]) + 1) % sigma                                    # the first part is (very likely) missing ...
+                    q[m - 3] = 250                                                    # ... so the bad letter near the end is never reached
+                elif t == 4:
+                    q[m - 1] = 250                                                    # in the rest / the last part
+                qs.append(q)
+        qs += [text[7:7 + k * 20].copy(), text[100:100 + k].copy()]                  # (ordinary queries beside them)
+        assert max(len(q) for q in qs) < 10000
+        qranks, qoff = pack(qs)
+        idx = engine.Index(text, sigma, [k])
+        oidx = orc.Index(text, sigma, [k])
+        clean = qranks.copy()
+        clean[clean >= sigma] = 0
+        o_off, o_pos, o_st, _ = oidx.search_batch(clean, qoff, mode=orc.MODE_INTENDED, n_threads=4)     # (the oracle has no bad letters: statuses of those queries are the engine's own)
+        res = engine.Result()
+        outs = []
+        for rep in range(3):
+            idx.stats_enable(True)
+            idx.search(np.tile(qranks, 1), qoff, result=res, flags=engine.SEARCH_KEEP_MASKS if rep == 2 else engine.SEARCH_DEFAULT)
+            outs.append(res.host())
+        for a, b in zip(outs[0], outs[1]):
+            assert np.array_equal(a, b), (sigma, k)                                  # one lane per query == one wave per query
+        assert np.array_equal(outs[2][0], outs[0][0]) and np.array_equal(outs[2][1], outs[0][1]) and np.array_equal(outs[2][2], outs[0][2])
+        ho, pos, st, kd = outs[0]
+        bad = np.array([bool((q >= sigma).any()) for q in qs])
+        # KMX_Q_BAD_RANK; OK when an earlier part was missing; SUBK_FANOUT when the bad letter sits in a rest that is never looked at
+        assert set(st[bad].tolist()) <= {0, 2, 4}
+        assert (st[bad] == 4).any() and (k < 13 or (st[bad] == 0).any())         # (parts only go missing where the k-mers are sparse)
+        good = ~bad
+        assert np.array_equal(st[good], o_st[good].astype(np.uint8))
+        for i in np.nonzero(good)[0]:
+            assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], o_pos[int(o_off[i]):int(o_off[i + 1])]), (sigma, k, i)
+            if st[i] == 0 and i % 5 == 0:
+                assert np.array_equal(pos[int(ho[i]):int(ho[i + 1])], orc.naive_scan(text, qs[i]))
+        assert (np.diff(ho)[bad] == 0).all()
+        if k == 13:
+            assert (st == 2).any()                                                   # KMX_Q_SUBK_FANOUT through a rest of one letter
+        idx.close()
+
+
+def test_prefix_slices_whose_positions_cluster(engine, orc):
+    """Big sub-k slices whose positions crowd into a small part of the text — a long homopolymer (one run of consecutive
+    positions), a periodic region (every 8th position, several runs) — through the block-level merge and the merge passes."""
     rng = np.random.default_rng(11)
     text = rng.integers(0, 4, 700_000).astype(np.uint8)
     text[100_000:220_000] = 0                                           # 120 000 x 'A': consecutive positions in ONE run
