@@ -1174,11 +1174,6 @@ __device__ __forceinline__ uint32_t staged_members(const uint32_t* __restrict__ 
 
 // INLINE_MORE: the survivors' further parts are checked right here (more registers, and the groups of a wave wait
 // for each other's survivors); otherwise k_validate_more does it afterwards from the survivor lists.
-//
-// A chunk = 128 candidates of every group's query: lane gl of the group takes the EIGHT CONSECUTIVE candidates
-// [128 c + 8 gl, 128 c + 8 gl + 8) — two 16-byte loads — and searches them in lockstep; its eight verdicts are byte gl of the
-// chunk's 128 mask bits (compressed_bitset.hpp:13-14: bit i = word i >> 6, bit i & 63), so the two mask words of a chunk are
-// assembled by sixteen one-byte LDS stores and read back with one 16-byte LDS load — no ballots, no per-round bookkeeping.
 template <bool INLINE_MORE>
 __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __restrict__ ix,
                                                         const uint32_t* __restrict__ arena,
@@ -1187,46 +1182,24 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                                                         uint64_t n_stitch, uint64_t* __restrict__ mask_words)
 {
     __shared__ __attribute__((aligned(16))) uint32_t stage[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VSTAGE];
-    __shared__ __attribute__((aligned(16))) uint8_t verdicts[KMX_BLOCK / KMX_WAVE][KMX_VGROUPS][KMX_VGROUP];
     const uint32_t lane = lane_id();
     const uint32_t wv = threadIdx.x / KMX_WAVE;
     const uint32_t g = lane / KMX_VGROUP, gl = lane % KMX_VGROUP;
-    static_assert(KMX_VGROUP == 16 && KMX_VGROUPS == 4 && KMX_VCH == 8, "a chunk is 16 lanes x 8 candidates = two mask words");
+    static_assert(KMX_VGROUP == 16 && KMX_VGROUPS == 4, "the mask word assembly below is written for four 16-lane groups");
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
-    // the bits of the chunk's four 32-bit quarters that lie below this lane's byte (8 gl): ranks of the survivors
-    uint32_t below[4];
-#pragma unroll
-    for (uint32_t w = 0; w < 4; ++w) below[w] = 8 * gl >= 32 * (w + 1) ? 0xFFFFFFFFu : 8 * gl <= 32 * w ? 0u : (1u << (8 * gl - 32 * w)) - 1u;
-    auto wsync = [] {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    };
 
-    // The chain list entry -> descriptor -> buckets is three dependent memory round trips per query; a wave that walked it
-    // once per round would spend its time waiting.  So the loop is software-pipelined: the descriptor of the NEXT round's
-    // query and the list entry of the round after it are loaded while this round's candidates are searched.
-    // (straight-line loads: an index past the end of the list reads the list's last query and is masked by `have`)
-    const uint64_t stride = n_waves * KMX_VGROUPS;
-    auto list_at = [&](uint64_t i) -> uint32_t { return d.stitch_list[min(i, n_stitch - 1)]; };
-    uint32_t q_next = list_at(wave * KMX_VGROUPS + g);
-    uint32_t q_after = list_at(wave * KMX_VGROUPS + stride + g);
-    uint32_t n_c0 = d.c0[q_next];
-    uint64_t n_src = d.src[q_next], n_p1 = d.p1[q_next], n_key = d.key[q_next], n_aux = d.aux[q_next];
-    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += stride) {
+    for (uint64_t i0 = wave * KMX_VGROUPS; i0 < n_stitch; i0 += n_waves * KMX_VGROUPS) {
         const uint64_t i = i0 + g;
         const bool have = i < n_stitch;
-        const uint32_t q = q_next;
-        const uint32_t c0 = n_c0;
-        const uint64_t src_raw = n_src;
-        const uint64_t p1 = n_p1;
-        const uint64_t p1src = n_key;
-        const uint64_t wbase = n_aux;
-        // the next round's descriptor (its query came with the previous round), and the list entry of the round behind it
-        q_next = q_after;
-        n_c0 = d.c0[q_next]; n_src = d.src[q_next]; n_p1 = d.p1[q_next]; n_key = d.key[q_next]; n_aux = d.aux[q_next];
-        q_after = list_at(i + 2 * stride);
+        // straight-line loads: a group past the end of the list reads the list's last query and is masked by `have`
+        const uint32_t q = d.stitch_list[min(i, n_stitch - 1)];
+        // one round of independent loads per group
+        const uint32_t c0 = d.c0[q];
+        const uint64_t src_raw = d.src[q];
+        const uint64_t p1 = d.p1[q];
+        const uint64_t p1src = d.key[q];
+        const uint64_t wbase = d.aux[q];
         const uint64_t src = src_raw & ~SRC_FLAGS;
         uint64_t* __restrict__ words = mask_words + wbase;
         const uint64_t sbase = wbase * 64;
@@ -1237,26 +1210,16 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
         // The staged bucket is padded with 0xFFFFFFFF (never a position) to the wave's largest power of
         // two, so that the search below is a fixed number of branch-free halving steps for all four groups.
         uint32_t P = (staged && pcnt > 1) ? (1u << (32 - __clz(int(pcnt - 1)))) : 1u;
-        const uint32_t n_ch = fast ? (c0 + KMX_VGROUP * KMX_VCH - 1) / (KMX_VGROUP * KMX_VCH) : 0u;     // chunks of this group's query
-        uint32_t max_ch = n_ch;
-        {
-            // (butterfly over the four groups: two exchanges)
-            P = max(P, uint32_t(__shfl_xor(int(P), KMX_VGROUP)));
-            max_ch = max(max_ch, uint32_t(__shfl_xor(int(max_ch), KMX_VGROUP)));
-            P = max(P, uint32_t(__shfl_xor(int(P), 2 * KMX_VGROUP)));
-            max_ch = max(max_ch, uint32_t(__shfl_xor(int(max_ch), 2 * KMX_VGROUP)));
+        uint32_t max_it = fast ? (c0 + KMX_VGROUP - 1) / KMX_VGROUP : 0u;
+        const uint32_t n_it = max_it;
+#pragma unroll
+        for (int e = 1; e < KMX_VGROUPS; ++e) {
+            P = max(P, uint32_t(__shfl_xor(int(P), e * KMX_VGROUP)));
+            max_it = max(max_it, uint32_t(__shfl_xor(int(max_it), e * KMX_VGROUP)));
         }
         P = uint32_t(__builtin_amdgcn_readfirstlane(int(P)));
-        max_ch = uint32_t(__builtin_amdgcn_readfirstlane(int(max_ch)));
+        max_it = uint32_t(__builtin_amdgcn_readfirstlane(int(max_it)));
         uint32_t* __restrict__ arr = stage[wv][g];
-        // the candidates of the first chunk are asked for BEFORE the filter bucket is staged: both buckets travel together
-        // (one pointer per lane and chunk, clamped to the bucket's last entry: a dead slot reads at most 7 entries past the
-        // bucket, inside the arena's KMX_ARENA_PAD)
-        static_assert(KMX_VCH * 4 + 16 <= KMX_ARENA_PAD, "the dead slots of a chunk must stay inside the arena's padding");
-        const uint32_t* __restrict__ cand = arena + src;
-        const uint32_t c_last = (fast && c0) ? c0 - 1u : 0u;
-        const uint32_t* __restrict__ cp = cand + min(gl * KMX_VCH, c_last);
-        u32x4 v0 = *reinterpret_cast<const u32x4_a4*>(cp), v1 = *reinterpret_cast<const u32x4_a4*>(cp + 4);
         {
             // four consecutive entries per lane and step: one 16-byte load (any element of the arena may be read 16 bytes
             // wide: its allocation is padded), one 16-byte LDS store; a lane past the bucket re-reads its last entry.
@@ -1273,23 +1236,40 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
                 *reinterpret_cast<u32x4*>(arr + t) = v;
             }
         }
-        wsync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
         uint32_t valid = 0;
+        const uint32_t lt_mask = (1u << gl) - 1u;
+        const uint32_t* __restrict__ cand = arena + src;
+        const uint32_t c_last = (fast && c0) ? c0 - 1u : 0u;
         const bool unstaged = fast && !staged;
-        uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + sbase : nullptr;
-        for (uint32_t ch = 0; ch < max_ch; ++ch) {
-            const uint32_t ci0 = ch * (KMX_VGROUP * KMX_VCH) + gl * KMX_VCH;          // this lane's first candidate
-            const uint32_t x[KMX_VCH] = {v0.x + delta, v0.y + delta, v0.z + delta, v0.w + delta, v1.x + delta, v1.y + delta, v1.z + delta, v1.w + delta};
-            const uint32_t* __restrict__ cp_cur = cp;
-            if (ch + 1 < max_ch) {                                      // (wave-uniform) the next chunk's candidates, while this one is searched
-                cp = cand + min(ci0 + KMX_VGROUP * KMX_VCH, c_last);
-                v0 = *reinterpret_cast<const u32x4_a4*>(cp); v1 = *reinterpret_cast<const u32x4_a4*>(cp + 4);
-            }
-            // bit r: this lane has a candidate in slot r
-            const uint32_t n_live = (fast && ci0 < c0) ? min(uint32_t(KMX_VCH), c0 - ci0) : 0u;
+        // KMX_VCH rounds of 16 candidates at a time: their loads go out together and their searches advance
+        // in lockstep, so one global and log2(P) + 1 LDS round trips are exposed per chunk instead of per round
+        for (uint32_t it0 = 0; it0 < max_it; it0 += KMX_VCH) {
+            const uint32_t nr = min(uint32_t(KMX_VCH), max_it - it0);  // wave-uniform
+            const uint32_t ci0 = it0 * KMX_VGROUP + gl;
+            uint32_t x[KMX_VCH];
+            // one pointer per lane and chunk, clamped to the bucket's last entry; the rounds are immediate offsets from it
+            // (a dead slot reads at most 7 x 16 entries past the bucket: inside the arena's KMX_ARENA_PAD)
+            static_assert((KMX_VCH - 1) * KMX_VGROUP * 4 + 16 <= KMX_ARENA_PAD, "the dead slots of a chunk must stay inside the arena's padding");
+            const uint32_t* __restrict__ cp = cand + min(ci0, c_last);
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) x[r] = cp[r * KMX_VGROUP];
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) x[r] += delta;
+            // bit r: this lane has a candidate in round r
+            const uint32_t n_live = (fast && ci0 < c0) ? min(uint32_t(KMX_VCH), (c0 - ci0 + KMX_VGROUP - 1) / KMX_VGROUP) : 0u;
             const uint32_t livem = (1u << n_live) - 1u;
-            uint32_t okm = staged_members<KMX_VCH>(arr, P, x) & livem;   // bit r: this lane's candidate r holds so far
+            uint32_t okm;                                               // bit r: this lane's candidate of round r holds so far
+            switch ((nr + 1) >> 1) {                                    // (straight-line code for 2, 4, 6 or 8 rounds)
+                case 1: okm = staged_members<2>(arr, P, x); break;
+                case 2: okm = staged_members<4>(arr, P, x); break;
+                case 3: okm = staged_members<6>(arr, P, x); break;
+                default: okm = staged_members<8>(arr, P, x); break;
+            }
+            okm &= livem;
             if (__any(unstaged)) {                                      // a filter bucket too long for LDS: searched where it lies
                 if (unstaged) {
                     okm = 0;
@@ -1302,46 +1282,48 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate(const KmxIndexDev* __res
             if (INLINE_MORE && __any(more && okm != 0)) {
                 // queries with further parts: the survivors of the filter, one per group at a time
 #pragma unroll 1
-                for (uint32_t r = 0; r < KMX_VCH; ++r) {
+                for (uint32_t r = 0; r < nr; ++r) {
                     uint32_t pend = uint32_t(__ballot(more && ((okm >> r) & 1u)) >> (KMX_VGROUP * g)) & 0xFFFFu;   // group-uniform
                     uint32_t dropped = 0;
                     while (__any(pend != 0)) {
                         if (pend) {
                             const uint32_t bsel = uint32_t(__ffs(int(pend))) - 1u;
-                            const uint32_t pc = arena[src + uint64_t(ch) * (KMX_VGROUP * KMX_VCH) + bsel * KMX_VCH + r];
+                            const uint32_t pc = arena[src + uint64_t(it0 + r) * KMX_VGROUP + bsel];
                             const bool good = stitch_parts_hold(ix, arena, qranks, qoff, q, pc, gl);
-                            const uint32_t verdicts16 = uint32_t(__ballot(good) >> (KMX_VGROUP * g)) & 0xFFFFu;
-                            if (verdicts16 != 0xFFFFu) dropped |= 1u << bsel;
+                            const uint32_t verdicts = uint32_t(__ballot(good) >> (KMX_VGROUP * g)) & 0xFFFFu;
+                            if (verdicts != 0xFFFFu) dropped |= 1u << bsel;
                             pend &= pend - 1;
                         }
                     }
                     if ((dropped >> gl) & 1u) okm &= ~(1u << r);
                 }
             }
-            // the chunk's 128 verdicts = two bitset words: byte gl is this lane's
-            verdicts[wv][g][gl] = uint8_t(okm);
-            wsync();
-            const u32x4 mw = *reinterpret_cast<const u32x4*>(verdicts[wv][g]);
-            if (gl == 0) {
-                if (ch < n_ch) {
-                    words[2 * ch] = (uint64_t(mw.y) << 32) | mw.x;
-                    if (ch * 128u + 64u < c0) words[2 * ch + 1] = (uint64_t(mw.w) << 32) | mw.z;
-                }
+            // 64 candidates = one bitset word = four rounds of 16-bit ballot slices; a chunk of KMX_VCH = 8 rounds is two
+            // words, and it0 is a multiple of 8, so which half-word a round fills is known at compile time
+            static_assert(KMX_VCH == 8, "the two-words-per-chunk assembly below");
+            uint32_t wq[4] = {0u, 0u, 0u, 0u};                          // {word A low, A high, word B low, B high}
+            uint32_t* __restrict__ sh_out = d.stitch_hits ? d.stitch_hits + sbase : nullptr;
+#pragma unroll
+            for (int r = 0; r < KMX_VCH; ++r) {
+                if (uint32_t(r) >= nr) break;
+                const bool ok = (okm & (1u << r)) != 0;
+                const uint32_t s16 = uint32_t(__ballot(ok) >> (KMX_VGROUP * g)) & 0xFFFFu;
+                // survivors, already compacted and ascending: what k_fill copies out for this query
+                if (ok && sh_out) sh_out[valid + uint32_t(__popc(s16 & lt_mask))] = x[r] - delta;
+                valid += uint32_t(__popc(s16));
+                wq[r >> 1] |= s16 << ((r & 1) * 16);
             }
-            if (okm && sh_out) {
-                // survivors, compacted and ascending (candidate order = lane order here): what k_fill copies out for this query
-                uint32_t at = valid + uint32_t(__popc(mw.x & below[0])) + uint32_t(__popc(mw.y & below[1])) + uint32_t(__popc(mw.z & below[2])) +
-                              uint32_t(__popc(mw.w & below[3]));
-                for (uint32_t left = okm; left; left &= left - 1)                 // (one survivor as a rule: its value is re-read, not selected)
-                    sh_out[at++] = cp_cur[uint32_t(__ffs(int(left))) - 1u];
+            if (gl == 0) {                                              // bit i = word i>>6, bit i&63
+                if (it0 < n_it) words[it0 >> 2] = (uint64_t(wq[1]) << 32) | wq[0];
+                if (it0 + 4 < n_it) words[(it0 >> 2) + 1] = (uint64_t(wq[3]) << 32) | wq[2];
             }
-            valid += uint32_t(__popc(mw.x)) + uint32_t(__popc(mw.y)) + uint32_t(__popc(mw.z)) + uint32_t(__popc(mw.w));
         }
         if (fast && gl == 0) {
             if ((c0 & 63) == 0) words[c0 / 64] = 0;                     // n_bits/64 + 1 words (compressed_bitset.hpp:23)
             d.cnt[q] = valid;
         }
-        wsync();                                                        // stage[] is reused by the next round
+        __builtin_amdgcn_wave_barrier();                                // stage[] is reused by the next round
+
     }
 }
 
