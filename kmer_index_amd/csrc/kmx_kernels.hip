@@ -1889,25 +1889,70 @@ __device__ void validate_big_wave(const KmxIndexDev* __restrict__ ix, const uint
                 r1 = uint32_t(upper_bound_dev<uint32_t>(arena + rsrc, rcnt, p_hi + rdl));
             }
             const uint32_t nb = min(uint32_t(KMX_WAVE), n_all - pb);
+            // The first window of the NEXT part's bucket is asked for while this part's is searched (cursor mode: a part's cursor
+            // only moves when the part itself is looked at, so the window is known a part ahead): the round per (tile, part) —
+            // one global round trip, then a dozen dependent LDS steps — no longer waits for the memory system every time.
+            constexpr uint32_t PRE_N = 4;                               // entries per lane of a prefetched window (8 measured slower: registers)
+            constexpr uint32_t PRE = PRE_N * KMX_WAVE;
+            auto next_part = [&](uint32_t j) { ++j; if (pb + j == a_e) ++j; return j; };
+            auto window_of = [&](uint32_t j, uint32_t& cur, uint32_t& s1, uint32_t& win) {
+                s1 = uint32_t(__shfl(int(r1), int(j))); cur = uint32_t(__shfl(int(r0), int(j))); win = uint32_t(__shfl(int(c_win), int(j)));
+            };
+            uint32_t pre[PRE_N];
+#pragma unroll
+            for (uint32_t u = 0; u < PRE_N; ++u) pre[u] = 0;
+            uint32_t pre_j = 0xFFFFFFFFu;                               // the part whose first window sits in pre[]
+            auto prefetch = [&](uint32_t j) {
+                pre_j = 0xFFFFFFFFu;
+                if (!cursors || j >= nb) return;
+                uint32_t cur, s1, win;
+                window_of(j, cur, s1, win);
+                const uint32_t W = min(win, s1 > cur ? s1 - cur : 0u);
+                if (W == 0 || W > PRE) return;
+                const uint32_t* __restrict__ bkn = arena + __shfl(rsrc, int(j));
+#pragma unroll
+                for (uint32_t u = 0; u < PRE_N; ++u) pre[u] = bkn[cur + min(lane + u * KMX_WAVE, W - 1)];
+                pre_j = j;
+            };
+            {
+                uint32_t j0 = 0;
+                if (pb + j0 == a_e) ++j0;
+                prefetch(j0);
+            }
             for (uint32_t j = 0; j < nb && __any(any); ++j) {
                 if (pb + j == a_e) continue;                            // the anchor itself
-                const uint32_t s1 = uint32_t(__shfl(int(r1), int(j)));
+                uint32_t s1, cur, win;
+                window_of(j, cur, s1, win);
                 const uint32_t dl = uint32_t(__shfl(int(rdl), int(j)));
                 const uint32_t* __restrict__ bk = arena + __shfl(rsrc, int(j));
                 const uint32_t x_hi = p_hi + dl;
-                uint32_t cur = uint32_t(__shfl(int(r0), int(j)));
-                const uint32_t win = uint32_t(__shfl(int(c_win), int(j)));
                 uint32_t und = 0;                                       // bit r: candidate r is alive and not yet decided for this part
                 uint32_t x[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) { x[r] = p[r] + dl; und |= uint32_t(alive[r]) << r; }
+                bool first_window = true;
                 for (;;) {                                              // windows of the bucket (wave-uniform control)
                     const uint32_t W = min(win, s1 > cur ? s1 - cur : 0u);
                     if (W == 0) break;
                     uint32_t P2 = 1;
                     while (P2 < W) P2 <<= 1;
                     wsync();                                            // the previous window has been searched
-                    for (uint32_t t = lane; t < P2; t += KMX_WAVE) wstage[t] = t < W ? bk[cur + t] : 0xFFFFFFFFu;
+                    if (first_window && pre_j == j) {
+                        // (this window came with the previous part; now the next part's is asked for)
+                        uint32_t mine[PRE_N];
+#pragma unroll
+                        for (uint32_t u = 0; u < PRE_N; ++u) mine[u] = pre[u];
+                        prefetch(next_part(j));
+#pragma unroll
+                        for (uint32_t u = 0; u < PRE_N; ++u) {
+                            const uint32_t t = lane + u * KMX_WAVE;
+                            if (t < P2) wstage[t] = t < W ? mine[u] : 0xFFFFFFFFu;
+                        }
+                    } else {
+                        if (first_window) prefetch(next_part(j));
+                        for (uint32_t t = lane; t < P2; t += KMX_WAVE) wstage[t] = t < W ? bk[cur + t] : 0xFFFFFFFFu;
+                    }
+                    first_window = false;
                     wsync();
                     const uint32_t last_val = wstage[W - 1];
                     uint32_t pos[R + 1];
