@@ -29,6 +29,8 @@ def build(force: bool = False, fill_e: int | None = None, verbose: bool = False,
     for knob in ("KMX_PSORT_MULTIWAY_RUNS", "KMX_LOOKUP_OCC", "KMX_PSB_CPT", "KMX_PMERGE_MIN_AVG", "KMX_PMERGE_REG_RUNS", "KMX_PMERGE_REG_LEN"):      # tuning experiments only
         if os.environ.get(knob):
             cmd.append(f"-D{knob}={int(os.environ[knob])}")
+    if os.environ.get("KMX_PHASE_TIMING"):                                      # measurement build: tools/probe_phases.py
+        cmd.append("-DKMX_PHASE_TIMING=1")
     if checked or os.environ.get("KMX_CHECKED"):
         cmd.append("-DKMX_CHECKED=1")
     cmd += [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]

@@ -828,7 +828,9 @@ def test_queries_of_very_many_parts_take_a_wave_each(engine, orc):
 
 def test_prefix_slices_whose_positions_cluster(engine, orc):
     """Big sub-k slices whose positions crowd into a small part of the text — a long homopolymer (one run of consecutive
-    positions), a periodic region (every 8th position, several runs) — through the block-level merge and the merge passes."""
+    positions), a periodic region (every 8th position, several runs) — through the block-level merge and the merge passes; with
+    k = 8 the slices have hundreds of runs: the distribution sort of such chunks (distribute_sort_lds) meets value buckets of more
+    than KMX_PBK_GIVE_UP positions there and hands the chunk to the bitonic network."""
     rng = np.random.default_rng(11)
     text = rng.integers(0, 4, 700_000).astype(np.uint8)
     text[100_000:220_000] = 0                                           # 120 000 x 'A': consecutive positions in ONE run
