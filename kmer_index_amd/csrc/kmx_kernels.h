@@ -88,7 +88,7 @@ void launch_fill(hipStream_t s, const FillVariant& v, bool rec32, const KmxIndex
                  const uint32_t* tile_q, const unsigned long long* total_dev, uint64_t n_tiles, const QueryDesc& d, uint32_t* out);
 void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, uint64_t n_stitch,
                     const uint64_t* mask_words, const uint64_t* hit_off, uint32_t* out);
-void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen);
+void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint32_t* banded, uint32_t* plen);
 // index construction on the device (see kmx_kernels.hip)
 void launch_build_phase1(hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t k, uint32_t sigma, uint64_t n_keys,
                          uint32_t* d_hist, uint64_t* d_scratch_u64, uint64_t* d_bsum, uint32_t* d_offs, uint32_t* d_cursor,
@@ -105,8 +105,23 @@ void launch_prefix_merge_small(hipStream_t s, const KmxIndexDev* ix, const uint6
                                const uint64_t* hit_off, const uint32_t* arena, uint32_t* out);
 // tile_off / tmp: only when the batch has slices beyond KMX_PSORT_BLOCK_CAP (launch_prefix_len + a scan give tile_off)
 // n_mid: how many of the listed slices have at most KMX_PSORT_MID_CAP positions (they take the 256-thread shape of the kernel)
+// The slices beyond the 256-thread shape that can be cut into BANDS (value ranges of the text: kmx_kernels.hip): banded[i] = 1 for
+// them, 0 for every other listed slice.  bands: cap_bands records of prefix_item_bytes() each, cap_bands >= 6 per listed slice beyond
+// KMX_PSORT_MID_CAP + (positions of the slices beyond KMX_PSORT_BLOCK_CAP) / prefix_band_target(); cuts: cap_cuts words (a slice that
+// finds no room stays with the chunks); used: two zeroed device counters (KMX_CTR_PSB_BANDS, KMX_CTR_PSB_CUTS)
+void launch_prefix_bands(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off,
+                         const uint32_t* arena, uint32_t* banded, void* bands, uint64_t cap_bands, uint32_t* cuts, uint64_t cap_cuts,
+                         unsigned long long* used);
+// items: room for cap_items records of prefix_item_bytes() each, cap_items >= (listed slices beyond KMX_PSORT_MID_CAP) + (positions of the
+// slices beyond KMX_PSORT_BLOCK_CAP) / KMX_PSORT_BLOCK_CAP; n_items: two zeroed device counters (KMX_CTR_PSB_MERGE, KMX_CTR_PSB_OTHER);
+// banded / bands / cuts / n_bands: what launch_prefix_bands left; dbg: the index's debug words
 void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
-                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp);
+                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp,
+                              void* items, uint64_t cap_items, unsigned long long* n_items, const uint32_t* banded, const void* bands, uint64_t cap_bands,
+                              const uint32_t* cuts, const unsigned long long* n_bands, unsigned long long* dbg);
+uint64_t prefix_item_bytes();
+uint64_t prefix_band_target();
+uint64_t prefix_band_runs();
 // one pairwise merge pass over the sorted chunks of the large slices; max_tiles >= tile_off[n_prefix]
 void launch_prefix_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* tile_off, uint64_t max_tiles,
                               const uint64_t* hit_off, uint32_t* out, uint32_t* tmp, uint32_t pass);

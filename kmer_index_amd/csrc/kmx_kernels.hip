@@ -3046,22 +3046,26 @@ __device__ __forceinline__ void merge_chunks(const KMX_LDS uint32_t* (&pa)[C], c
             vb[u] = pb[u] < b_end[u] ? vb[u] : KMX_PM_SENT;
         }
     }
+    auto step = [&](int j) {
 #pragma unroll
-    for (int j = 0; j < EMAX; ++j) {
-        if (uint32_t(j) < E) {                                    // uniform over the cooperating threads
-#pragma unroll
-            for (int u = 0; u < C; ++u) {
-                const bool c = va[u] < vb[u];
-                x[u][j] = c ? va[u] : vb[u];
-                const KMX_LDS uint32_t* t = (c ? pa[u] : pb[u]) + 1;
-                uint32_t nv = *t;
-                if (CHECKED) nv = t < (c ? a_end[u] : b_end[u]) ? nv : KMX_PM_SENT;
-                pa[u] = c ? t : pa[u];
-                pb[u] = c ? pb[u] : t;
-                va[u] = c ? nv : va[u];
-                vb[u] = c ? vb[u] : nv;
-            }
+        for (int u = 0; u < C; ++u) {
+            const bool c = va[u] < vb[u];
+            x[u][j] = c ? va[u] : vb[u];
+            const KMX_LDS uint32_t* t = (c ? pa[u] : pb[u]) + 1;
+            uint32_t nv = *t;
+            if (CHECKED) nv = t < (c ? a_end[u] : b_end[u]) ? nv : KMX_PM_SENT;
+            pa[u] = c ? t : pa[u];
+            pb[u] = c ? pb[u] : t;
+            va[u] = c ? nv : va[u];
+            vb[u] = c ? vb[u] : nv;
         }
+    };
+    // E is odd and at least 3 (merge_runs_lds' callers): step 0, then two steps per (uniform) test of E
+    static_assert(EMAX % 2 == 1 && EMAX >= 3, "an odd chunk length");
+    step(0);
+#pragma unroll
+    for (int j = 1; j + 1 < EMAX; j += 2) {
+        if (uint32_t(j + 1) < E) { step(j); step(j + 1); }
     }
 }
 
@@ -3070,10 +3074,22 @@ __device__ __forceinline__ void merge_chunks(const KMX_LDS uint32_t* (&pa)[C], c
 // tables of ALL rounds are written up front, wave r the table of round r, so that a round is partition - merge - barrier -
 // write back - barrier with no serial table phase in it; TSTRIDE == 0 (one wave): the table of a round is made at its start.
 // C: chunks per thread and round (thread t takes chunks t, t + NT, ...), merged in lockstep — see merge_chunks.
+#ifdef KMX_PHASE_TIMING
+// (measurement build only) thread 0 of a block adds the shader-clock cycles between two marks to a word of the index's debug block
+#define KMX_MARK(word)                                                                                                \
+    do {                                                                                                              \
+        if (kmx_timing && threadIdx.x == 0) { const long long now__ = clock64(); atomicAdd(kmx_timing + (word), (unsigned long long)(now__ - kmx_t0)); kmx_t0 = now__; } \
+    } while (0)
+#else
+#define KMX_MARK(word) do { } while (0)
+#endif
 template <int EMAX, int NT, int TSTRIDE, int C, typename Sync>
 __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R, uint32_t len,
-                                               uint32_t E, uint32_t rcp, uint32_t tid, Sync sync)
+                                               uint32_t E, uint32_t rcp, uint32_t tid, Sync sync, unsigned long long* kmx_timing = nullptr)
 {
+#ifdef KMX_PHASE_TIMING
+    long long kmx_t0 = clock64();
+#endif
     constexpr bool PRETAB = TSTRIDE > 0;
     constexpr uint32_t KMX_PM_TSTRIDE = TSTRIDE;
     KMX_LDS uint32_t* lb = (KMX_LDS uint32_t*)buf;
@@ -3088,6 +3104,7 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
         }
         sync();
     }
+    KMX_MARK(6);
     uint32_t w = 1, ngroups = R, rnd = 0;
     bool first = true;
     while (ngroups > 1) {
@@ -3137,22 +3154,29 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
         // candidate beyond the bracket reads a clamped entry and is refused)
         uint32_t lo[C];
         {
+            // (every thread halves its OWN bracket: the probes of a wave's threads then fall wherever their diagonals put them.  With
+            //  common strides — lo + 2^k for everybody — the probes of a step were a multiple of 2^k apart: one LDS bank for the
+            //  whole wave in the steps of 32 words and more, a third of the pipe's rate in this phase)
             uint32_t hi[C];
 #pragma unroll
             for (int u = 0; u < C; ++u) { lo[u] = dg[u] > nb[u] ? dg[u] - nb[u] : 0u; hi[u] = min(dg[u], na[u]); }
-            for (uint32_t st = steps ? 1u << (steps - 1) : 0u; st; st >>= 1) {
-                uint32_t av[C], bv[C], cand[C];
+            for (uint32_t it = 0; it < steps; ++it) {                 // steps: bits of the longest bracket of the round
+                uint32_t av[C], bv[C], mid[C];
 #pragma unroll
                 for (int u = 0; u < C; ++u) {
-                    cand[u] = lo[u] + st;
-                    const uint32_t cc = min(cand[u], hi[u]);          // A[cand - 1] < B[dg - cand]: cand is not past the crossing
-                    av[u] = pA[u][int32_t(cc) - 1];
-                    bv[u] = (pB[u] + dg[u])[-int32_t(cc)];
+                    mid[u] = (lo[u] + hi[u]) >> 1;                    // < hi while the bracket is open: A[mid], B[dg - 1 - mid] exist
+                    av[u] = pA[u][mid[u]];
+                    bv[u] = (pB[u] + dg[u])[-int32_t(mid[u]) - 1];
                 }
 #pragma unroll
-                for (int u = 0; u < C; ++u) lo[u] = ((cand[u] <= hi[u]) & (av[u] < bv[u])) ? cand[u] : lo[u];
+                for (int u = 0; u < C; ++u) {
+                    const bool open = lo[u] < hi[u], up = av[u] < bv[u];     // A[mid] < B[dg - 1 - mid]: the crossing is above mid
+                    lo[u] = (open & up) ? mid[u] + 1 : lo[u];
+                    hi[u] = (open & !up) ? mid[u] : hi[u];
+                }
             }
         }
+        KMX_MARK(7);                                               // pair lookup + merge-path searches
         // (the two kinds of round as two copies of "merge, barrier, write back": one set of registers each)
         auto round = [&](auto checked) {
             uint32_t x[C][EMAX];
@@ -3163,15 +3187,28 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
 #pragma unroll
             for (int u = 0; u < C; ++u) { qa[u] = pA[u] + lo[u]; qb[u] = pB[u] + (dg[u] - lo[u]); ea[u] = lb + mi[u]; eb[u] = lb + e[u]; }
             merge_chunks<EMAX, decltype(checked)::value, C>(qa, qb, ea, eb, E, x);
+            KMX_MARK(8);                                           // the E merge steps
             sync();                                                // every read of the round is done
+            KMX_MARK(9);                                           // barrier wait
 #pragma unroll
             for (int u = 0; u < C; ++u) {
                 KMX_LDS uint32_t* o = lb + (s[u] + p[u] + dg[u]);
+                // (a chunk is whole — E outputs — unless it is the last of its pair: when every chunk of the wave is whole or
+                //  idle the stores run under ONE predicate, not one per element)
+                if (__all(nout[u] == E || nout[u] == 0)) {
+                    if (nout[u]) {
+                        o[0] = x[u][0];
 #pragma unroll
-                for (int j = 0; j < EMAX; ++j)
-                    if (uint32_t(j) < E) {
-                        if (uint32_t(j) < nout[u]) o[j] = x[u][j];
+                        for (int j = 1; j + 1 < EMAX; j += 2)              // (E is odd: pairs behind the first — one test, one two-word LDS store)
+                            if (uint32_t(j + 1) < E) { o[j] = x[u][j]; o[j + 1] = x[u][j + 1]; }
                     }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < EMAX; ++j)
+                        if (uint32_t(j) < E) {
+                            if (uint32_t(j) < nout[u]) o[j] = x[u][j];
+                        }
+                }
             }
         };
         if (first) round(std::true_type{});
@@ -3184,6 +3221,7 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
             if (tid < np2 && nxt[4 * tid + 2] == nxt[4 * tid + 1]) lb[nxt[4 * tid + 1] + 2 * tid + 1] = KMX_PM_SENT;
         }
         sync();
+        KMX_MARK(10);                                              // write back + sentinels + barrier
         w <<= 1;
         ngroups = npairs;
         first = false;
@@ -3201,7 +3239,7 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
 // All of them read the slice where it lies in the arena and write `out`; k_fill leaves those slots alone.
 // k_prefix_len: tiles of the slices that need merge passes (0 for the others).
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t n_prefix,
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t n_prefix, const uint32_t* __restrict__ banded,
                                                           uint32_t* __restrict__ plen)
 {
     const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
@@ -3211,7 +3249,8 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t 
     // large slices: output tiles of k_prefix_merge_pass (the scan of these is both the tile table and, times the tile, the
     // slice's place in the scratch buffer); the others are finished by k_prefix_sort_small / k_prefix_sort_block
     // (a slice of ONE run is in order as k_fill copies it: no chunks, no passes)
-    plen[i] = (len > KMX_PSORT_BLOCK_CAP && d.c0[q] >= 2) ? (len + KMX_PM_TILE - 1) / KMX_PM_TILE : 0u;
+    // (... and a slice cut into bands is finished by k_prefix_merge_band: no chunks, no passes)
+    plen[i] = (len > KMX_PSORT_BLOCK_CAP && d.c0[q] >= 2 && !banded[i]) ? (len + KMX_PM_TILE - 1) / KMX_PM_TILE : 0u;
 }
 
 // PREFIX queries with a short slice (<= KMX_PSORT_CAP positions), one wave per query.  The slice is the concatenation of
@@ -3544,7 +3583,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_pass(QueryDesc d, ui
 // (kernel, device), not once per process (an index may live on any device of the node, replicas on several).
 static void allow_big_lds(const void* fn, size_t bytes, int which)
 {
-    static std::atomic<uint64_t> done[2] = {{0}, {0}};
+    static std::atomic<uint64_t> done[3] = {{0}, {0}, {0}};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
     const uint64_t bit = uint64_t(1) << (dev & 63);
@@ -3709,9 +3748,9 @@ void launch_compact(hipStream_t s, const uint32_t* arena, const QueryDesc& d, ui
     hipLaunchKernelGGL(k_compact, dim3(blocks ? blocks : 1), dim3(KMX_BLOCK), 0, s, arena, d, n_stitch, mask_words, hit_off, out);
 }
 
-void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, uint32_t* plen)
+void launch_prefix_len(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint32_t* banded, uint32_t* plen)
 {
-    hipLaunchKernelGGL(k_prefix_len, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, plen);
+    hipLaunchKernelGGL(k_prefix_len, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, d, n_prefix, banded, plen);
 }
 
 
@@ -3735,87 +3774,744 @@ struct PsbShape {
 typedef PsbShape<1024, KMX_PSORT_BLOCK_CAP, 128> PsbBig;
 typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
 
+// distribute_sort_lds — the std::sort of kmer_index_result.hpp:258 for a chunk of MORE runs than merge_runs_lds takes (hundreds of
+// short buckets: a sub-k query far below k on an element without prefix levels) whose positions are SPREAD over the text (the
+// buckets of all k-mers with one prefix are: a k-mer family occurs all over a text without long repeats), as a distribution
+// sort instead of a bitonic network over the whole chunk (measured: 256 runs of 95 positions 8.4 ms against 49 per 5e4 slices;
+// for the few long runs the merge takes it was no faster, DESIGN A): a position's value bucket is (position * NB) / n — monotone —
+// so (1) every thread counts its positions into the NB buckets (LDS atomics that return the slot inside the bucket), (2) a scan
+// of the counts gives every bucket its place, (3) the positions are scattered to place + slot, (4) every bucket — three or four
+// positions on average — is put in order from registers by an 8-input sorting network (insertion in LDS for the rare longer
+// one), (5) the chunk leaves coalesced.  Returns false — nothing written but the counters — when some bucket holds more than
+// KMX_PBK_GIVE_UP positions (a repeat of the text: the caller sorts the chunk with the bitonic network instead).
+// out: CAP words, cnt: NB / 2 words (two 16-bit counters per word), wsum: THREADS / 64 + 2 words.
+#define KMX_PBK_NB 8192
+#define KMX_PBK_GIVE_UP 48
+template <int THREADS, int CAP>
+__device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wsum,
+                                                    const uint32_t* __restrict__ seg, uint32_t c_len, uint64_t n_text, uint32_t tid)
+{
+    constexpr int E = CAP / THREADS;                              // positions per thread
+    constexpr int BPT = KMX_PBK_NB / THREADS;                     // buckets per thread in the scan and the bucket sorts
+    static_assert(CAP % THREADS == 0 && KMX_PBK_NB % THREADS == 0 && BPT % 2 == 0 && BPT <= 8, "two counters per word, a thread's counters in one 16-byte read");
+    static_assert(CAP <= 65535 && KMX_PBK_NB <= (1 << 13), "16-bit counters; bucket and slot share a word");
+    const uint32_t mul = uint32_t((uint64_t(KMX_PBK_NB) << 32) / n_text);     // floor: (p * mul) >> 32 < NB for every p < n
+    for (uint32_t i = tid; i < KMX_PBK_NB / 2; i += THREADS) cnt[i] = 0;
+    if (tid == 0) wsum[THREADS / 64] = 0;                         // the longest bucket
+    __syncthreads();
+    // 1. count; the slot inside its bucket is all a position keeps (16 bits: two per register — the position itself is read
+    //    again for the scatter, out of L2, and its bucket recomputed: registers are what this shape is short of)
+    uint32_t slots[E / 2];
+    static_assert(E % 2 == 0, "two slots per register");
+#pragma unroll
+    for (int j2 = 0; j2 < E / 2; ++j2) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t i = uint32_t(2 * j2 + h) * THREADS + tid;
+            uint32_t old = 0, sh = 0;
+            if (i < c_len) {
+                const uint32_t b = __umulhi(seg[i], mul);
+                sh = 16u * (b & 1u);
+                old = atomicAdd(&cnt[b >> 1], 1u << sh);
+            }
+            packed |= ((old >> sh) & 0xFFFFu) << (16 * h);
+        }
+        slots[j2] = packed;
+    }
+    __syncthreads();
+    // 2. exclusive scan of the counts: thread t owns buckets [BPT t, BPT t + BPT)
+    uint32_t c[BPT], st[BPT];
+    {
+        const uint32_t* mine = cnt + tid * (BPT / 2);
+        uint32_t total = 0, longest = 0;
+#pragma unroll
+        for (int u = 0; u < BPT / 2; ++u) {
+            const uint32_t w = mine[u];
+            c[2 * u] = w & 0xFFFFu; c[2 * u + 1] = w >> 16;
+        }
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) { st[u] = total; total += c[u]; longest = max(longest, c[u]); }
+        uint32_t inc = total;
+        const uint32_t lane = tid & 63u, wv = tid / 64u;
+#pragma unroll
+        for (uint32_t o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+            longest = max(longest, uint32_t(__shfl_xor(int(longest), int(o))));
+        }
+        if (lane == 63) wsum[wv] = inc;
+        if (lane == 0 && longest > KMX_PBK_GIVE_UP) atomicMax(&wsum[THREADS / 64], longest);
+        __syncthreads();
+        uint32_t carry = 0;
+        for (uint32_t w2 = 0; w2 < wv; ++w2) carry += wsum[w2];
+        const bool give_up = wsum[THREADS / 64] != 0;
+        __syncthreads();                                          // (wsum is read: the counters may be overwritten by the places)
+        if (give_up) return false;
+        const uint32_t base = carry + inc - total;
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) st[u] += base;
+        uint32_t* mine_w = cnt + tid * (BPT / 2);
+#pragma unroll
+        for (int u = 0; u < BPT / 2; ++u) mine_w[u] = st[2 * u] | (st[2 * u + 1] << 16);      // places < CAP <= 65535
+    }
+    __syncthreads();
+    // 3. scatter
+#pragma unroll
+    for (int j = 0; j < E; ++j) {
+        const uint32_t i = uint32_t(j) * THREADS + tid;
+        if (i < c_len) {
+            const uint32_t p = seg[i];
+            const uint32_t b = __umulhi(p, mul), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const uint32_t place = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
+            out[place + slot] = p;
+        }
+    }
+    __syncthreads();
+    // 4. every bucket in order (a thread's BPT buckets are its own: no barrier between them)
+#pragma unroll 1
+    for (int u = 0; u < BPT; ++u) {
+        const uint32_t n_b = c[u];
+        uint32_t* __restrict__ bk = out + st[u];
+        if (n_b >= 2 && n_b <= 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t) v[t] = t < n_b ? bk[t] : 0xFFFFFFFFu;
+            auto cx = [&](int a, int b2) { const uint32_t lo = min(v[a], v[b2]), hi = max(v[a], v[b2]); v[a] = lo; v[b2] = hi; };
+            cx(0, 1); cx(2, 3); cx(4, 5); cx(6, 7);
+            cx(0, 2); cx(1, 3); cx(4, 6); cx(5, 7);
+            cx(1, 2); cx(5, 6); cx(0, 4); cx(3, 7);
+            cx(1, 5); cx(2, 6);
+            cx(1, 4); cx(3, 6);
+            cx(2, 4); cx(3, 5);
+            cx(3, 4);
+#pragma unroll
+            for (uint32_t t = 0; t < 8; ++t)
+                if (t < n_b) bk[t] = v[t];
+        } else if (n_b > 8) {
+            for (uint32_t i = 1; i < n_b; ++i) {                 // (rare: insertion where it lies)
+                const uint32_t key = bk[i];
+                uint32_t j = i;
+                while (j > 0 && bk[j - 1] > key) { bk[j] = bk[j - 1]; --j; }
+                bk[j] = key;
+            }
+        }
+    }
+    __syncthreads();
+    return true;
+}
+
+// One chunk of a slice through a block: `seg` the chunk where it lies in the arena, `dst` where it goes, runs[0 .. Rc] the Rc + 1
+// entries of the offset table that bound its runs (entries are absolute: `base` = the table's value at the chunk's first position).
 template <int THREADS, int CAP, int RUNS, bool MID>
-__global__ __launch_bounds__(THREADS) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
+__device__ __forceinline__ void psb_chunk(uint32_t* __restrict__ sbuf, uint32_t* __restrict__ bnd, uint32_t* __restrict__ ptab,
+                                          const uint32_t* __restrict__ seg, uint32_t* __restrict__ dst, const KMX_GLOBAL uint32_t* runs,
+                                          uint32_t base, uint32_t c_len, uint32_t Rc, uint64_t n_text, uint32_t tid)
+{
+    typedef PsbShape<THREADS, CAP, RUNS> Shape;
+    const bool merge = Rc <= RUNS;
+    if constexpr (!MID) if (!merge) {
+        // more runs than the merge takes: the distribution sort (it gives up on a repeat of the text: the network below)
+        __shared__ uint32_t wsum[THREADS / 64 + 2];
+        if (distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, seg, c_len, n_text, tid)) {
+            for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
+            __syncthreads();
+            return;
+        }
+    }
+    if (merge && tid <= Rc) {
+        const uint32_t o = runs[tid];
+        bnd[tid] = o <= base ? 0u : min(o - base, c_len);
+    }
+    uint32_t n2 = 2;
+    while (n2 < c_len) n2 <<= 1;
+    const uint32_t n_stage = merge ? c_len : n2;
+    constexpr uint32_t QPT = (CAP / 4 + THREADS - 1) / THREADS;       // quads per thread
+    {
+        // staging: four consecutive positions per thread and step as ONE 16-byte load (any alignment of the slice: global
+        // loads only need 4 bytes) and one 16-byte LDS store, all of a thread's loads in flight before its first store —
+        // a load-wait-store loop per position was 30 % of a 24 K slice's time (tools/probe_phases.py)
+        u32x4 v[QPT];
+#pragma unroll
+        for (uint32_t u = 0; u < QPT; ++u) {
+            const uint32_t t = (u * THREADS + tid) * 4;
+            if (t + 3 < c_len) {
+                v[u] = *reinterpret_cast<const u32x4_a4*>(seg + t);
+            } else {
+                v[u].x = t + 0 < c_len ? seg[t + 0] : 0xFFFFFFFFu;
+                v[u].y = t + 1 < c_len ? seg[t + 1] : 0xFFFFFFFFu;
+                v[u].z = t + 2 < c_len ? seg[t + 2] : 0xFFFFFFFFu;
+                v[u].w = 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < QPT; ++u) {
+            const uint32_t t = (u * THREADS + tid) * 4;
+            if (t < n_stage) *reinterpret_cast<u32x4*>(sbuf + t) = v[u];  // (up to three sentinels behind a merge's slice: inside its slack)
+        }
+    }
+    __syncthreads();
+    if (merge) {
+        constexpr uint32_t CH = THREADS * Shape::CPT;                                     // chunks of a round
+        const uint32_t E = max(3u, ((c_len + (CH - (Rc + 1) / 2) - 1) / (CH - (Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
+        merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+    } else {
+        bitonic_lds(sbuf, n2, tid, uint32_t(THREADS), [] { __syncthreads(); });
+    }
+    {
+        u32x4 v[QPT];
+#pragma unroll
+        for (uint32_t u = 0; u < QPT; ++u) {
+            const uint32_t t = (u * THREADS + tid) * 4;
+            if (t < c_len) v[u] = *reinterpret_cast<const u32x4*>(sbuf + t);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < QPT; ++u) {
+            const uint32_t t = (u * THREADS + tid) * 4;
+            if (t + 3 < c_len) {
+                *reinterpret_cast<u32x4_a4*>(dst + t) = v[u];
+            } else if (t < c_len) {
+                dst[t] = v[u].x;
+                if (t + 1 < c_len) dst[t + 1] = v[u].y;
+                if (t + 2 < c_len) dst[t + 2] = v[u].z;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// The 256-thread shape: slices of at most KMX_PSORT_MID_CAP positions (one chunk each), a block per slice, four blocks per CU.
+template <int THREADS, int CAP, int RUNS>
+__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
                                                                 const uint64_t* __restrict__ qoff, QueryDesc d,
                                                                 uint64_t n_prefix,
                                                                 const uint64_t* __restrict__ hit_off,
                                                                 const uint32_t* __restrict__ arena,
-                                                                uint32_t* __restrict__ out,
-                                                                const uint64_t* __restrict__ tile_off,
-                                                                uint32_t* __restrict__ tmp)
+                                                                uint32_t* __restrict__ out)
 {
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
     extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
     __shared__ uint32_t bnd[RUNS + 1];
     __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
-    __shared__ uint32_t runs[2];
     const uint32_t tid = threadIdx.x;
     for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
         const uint32_t q = d.prefix_list[i];
         const uint32_t R = d.c0[q];
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-        if ((len <= KMX_PSORT_MID_CAP) != MID) continue;                                  // the other shape's (block-uniform)
-        const uint32_t n_chunks = (len + CAP - 1) / CAP;
-        // where the chunks go: `out`, or the scratch buffer when the slice needs an odd number of merge passes
-        uint32_t* __restrict__ sorted = (!MID && (prefix_merge_passes(len) & 1u)) ? tmp + tile_off[i] * KMX_PM_TILE : out + hit_off[q];
+        if (len > CAP) continue;                                                          // the 1024-thread kernels' (block-uniform)
         const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);   // R + 1 run boundaries
-        const uint32_t offs0 = offs[0];
-        for (uint32_t c = blockIdx.y; c < n_chunks; c += gridDim.y) {
-            const uint32_t c_lo = c * CAP;
-            const uint32_t c_len = min(uint32_t(CAP), len - c_lo);
-            const uint32_t* __restrict__ seg = arena + (d.src[q] & ~SRC_FLAGS) + c_lo;    // where the slice lies
-            if (tid == 0) {
-                // the run that holds the chunk's first position, the first boundary at or behind its end
-                const uint32_t r0 = uint32_t(upper_bound_dev<uint32_t>(offs, uint64_t(R) + 1, offs0 + c_lo)) - 1;
-                const uint32_t r1 = uint32_t(lower_bound_dev<uint32_t>(offs, uint64_t(R) + 1, offs0 + c_lo + c_len));
-                runs[0] = r0;
-                runs[1] = r1 - r0;
+        psb_chunk<THREADS, CAP, RUNS, true>(sbuf, bnd, ptab, arena + (d.src[q] & ~SRC_FLAGS), out + hit_off[q], offs, offs[0], len, R, ix->n, tid);
+    }
+}
+
+// The chunks of the longer slices (up to KMX_PSORT_BLOCK_CAP positions each) as ITEMS: what a 1024-thread block needs to know about
+// one chunk, in one 32-byte record — written once by k_prefix_items (a wave per slice, a lane per chunk), so that the blocks
+// that do the work find a chunk's header with ONE load asked for two chunks ahead instead of five dependent round trips (list
+// entry -> descriptor -> planner -> offset table -> run search) in front of every chunk: 8 K of a 24 K-position slice's 90 K
+// cycles (tools/probe_phases.py).  Chunks the merge takes (at most RUNS runs) are listed from the front of the item array,
+// the others from its back.
+struct PsbItem {
+    uint64_t seg;                  // the chunk's first position in the arena
+    uint64_t dst;                  // where it goes: an index into `out`, or with KMX_PSB_TMP into the scratch buffer of the merge passes
+    const uint32_t* runs;          // offset-table entries of its runs (n_runs + 1 of them)
+    uint32_t len_runs;             // length (16 bits; <= 32768) | min(runs, 0xFFFF) << 16
+    uint32_t base;                 // the offset table's value at the chunk's first position
+};
+static_assert(sizeof(PsbItem) == 32, "one record = two 16-byte loads");
+#define KMX_PSB_TMP (1ull << 63)
+
+template <int CAP, int RUNS>
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_items(const KmxIndexDev* __restrict__ ix, const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                            uint64_t n_prefix, const uint64_t* __restrict__ hit_off, const uint32_t* __restrict__ banded,
+                                                            const uint64_t* __restrict__ tile_off, PsbItem* __restrict__ items, uint64_t cap_items,
+                                                            unsigned long long* __restrict__ n_items)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t i = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    if (i >= n_prefix || banded[i]) return;                                               // (k_prefix_merge_band's)
+    const uint32_t q = d.prefix_list[i];
+    const uint32_t R = d.c0[q];
+    const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    if (len <= KMX_PSORT_MID_CAP) return;                                                 // the 256-thread kernel's
+    const uint32_t n_chunks = (len + CAP - 1) / CAP;
+    // where the chunks go: `out`, or the scratch buffer when the slice needs an odd number of merge passes
+    const uint64_t dst0 = (prefix_merge_passes(len) & 1u) ? (tile_off[i] * KMX_PM_TILE) | KMX_PSB_TMP : hit_off[q];
+    const uint64_t src0 = d.src[q] & ~SRC_FLAGS;
+    const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);       // R + 1 run boundaries
+    const uint32_t offs0 = offs[0];
+    for (uint32_t c0 = 0; c0 < n_chunks; c0 += KMX_WAVE) {
+        const uint32_t c = c0 + lane;
+        const bool active = c < n_chunks;
+        const uint32_t c_lo = c * CAP, c_len = active ? min(uint32_t(CAP), len - c_lo) : 0u;
+        uint32_t r0 = 0, Rc = R;
+        if (n_chunks > 1 && active) {
+            // the run that holds the chunk's first position, the first boundary at or behind its end
+            r0 = uint32_t(upper_bound_dev<uint32_t>(offs, uint64_t(R) + 1, offs0 + c_lo)) - 1;
+            Rc = uint32_t(lower_bound_dev<uint32_t>(offs, uint64_t(R) + 1, offs0 + c_lo + c_len)) - r0;
+        }
+        const bool merge = active && Rc <= RUNS;
+        const uint64_t mb = __ballot(merge), ob = __ballot(active && !merge);
+        unsigned long long bm = 0, bo = 0;
+        if (lane == 0) {
+            if (mb) bm = atomicAdd(&n_items[0], (unsigned long long)__popcll(mb));
+            if (ob) bo = atomicAdd(&n_items[1], (unsigned long long)__popcll(ob));
+        }
+        bm = __shfl(bm, 0); bo = __shfl(bo, 0);
+        if (active) {
+            const uint64_t below = (uint64_t(1) << lane) - 1;
+            const uint64_t at = merge ? bm + uint64_t(__popcll(mb & below)) : cap_items - 1 - (bo + uint64_t(__popcll(ob & below)));
+            if (at < cap_items) {
+                PsbItem it;
+                it.seg = src0 + c_lo;
+                it.dst = dst0 + c_lo;
+                it.runs = (const uint32_t*)(offs + r0);
+                it.len_runs = c_len | (min(Rc, 0xFFFFu) << 16);
+                it.base = offs0 + c_lo;
+                items[at] = it;
             }
-            __syncthreads();
-            const uint32_t r0 = __builtin_amdgcn_readfirstlane(runs[0]), Rc = __builtin_amdgcn_readfirstlane(runs[1]);
-            const bool merge = Rc <= RUNS;
-            if (merge && tid <= Rc) {
-                const uint32_t o = offs[r0 + tid] - offs0;
-                bnd[tid] = o <= c_lo ? 0u : min(o - c_lo, c_len);
-            }
-            uint32_t n2 = 2;
-            while (n2 < c_len) n2 <<= 1;
-            const uint32_t n_stage = merge ? c_len : n2;
-            for (uint32_t t = tid; t < n_stage; t += THREADS) sbuf[t] = t < c_len ? seg[t] : 0xFFFFFFFFu;
-            __syncthreads();
-            if (merge) {
-                constexpr uint32_t CH = THREADS * Shape::CPT;                                     // chunks of a round
-                const uint32_t E = max(3u, ((c_len + (CH - (Rc + 1) / 2) - 1) / (CH - (Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
-                merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, Rc, c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
-            } else {
-                bitonic_lds(sbuf, n2, tid, uint32_t(THREADS), [] { __syncthreads(); });
-            }
-            uint32_t* __restrict__ dst = sorted + c_lo;
-            for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
-            __syncthreads();
         }
     }
 }
 
-// n_mid of the n_prefix listed queries have slices of at most KMX_PSORT_MID_CAP positions
+// The items the merge takes, one block per CU walking its share of them as a PIPELINE: while chunk j is merged in LDS, chunk
+// j + 1's positions (asked for right behind j's staging barrier) arrive in registers and item j + 2's record is on its way, and
+// j's copy-out leaves as stores nobody waits for.  A 128-KB block owns its CU alone, so nothing else overlaps its memory phases:
+// without this, loading a chunk, its header and storing it were half of the block's time with the LDS pipe idle.
+#ifndef KMX_PSB_PREFETCH
+#define KMX_PSB_PREFETCH 8     // quads of the next chunk a thread holds in registers while it merges (of CAP / 4 / THREADS: the others are
+#endif                         // asked for when the chunk is staged)
+template <int THREADS, int CAP, int RUNS>
+__global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem* __restrict__ items, const unsigned long long* __restrict__ n_items_p,
+                                                                 const uint32_t* __restrict__ arena, uint32_t* __restrict__ out,
+                                                                 uint32_t* __restrict__ tmp, unsigned long long* kmx_timing)
+{
+    typedef PsbShape<THREADS, CAP, RUNS> Shape;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
+    __shared__ uint32_t bnd[RUNS + 1];
+    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
+    constexpr uint32_t QPT = (CAP / 4 + THREADS - 1) / THREADS;       // quads per thread
+    constexpr uint32_t PF = KMX_PSB_PREFETCH < QPT ? KMX_PSB_PREFETCH : QPT;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_items = *n_items_p, G = gridDim.x;
+    uint64_t j = blockIdx.x;
+    if (j >= n_items) return;
+#ifdef KMX_PHASE_TIMING
+    long long kmx_t0 = clock64();
+#endif
+    struct Hdr { const uint32_t* seg; uint32_t* dst; const KMX_GLOBAL uint32_t* runs; uint32_t c_len, Rc, base; };
+    const u32x4* recs = reinterpret_cast<const u32x4*>(items);
+    auto header = [&](const u32x4& a, const u32x4& b) {             // (a record is the same in every lane: say so)
+        Hdr h;
+        auto u = [](uint32_t x) { return uint32_t(__builtin_amdgcn_readfirstlane(x)); };            // (the builtin returns a SIGNED int)
+        const uint64_t seg = uint64_t(u(a.x)) | uint64_t(u(a.y)) << 32;
+        const uint64_t dst = uint64_t(u(a.z)) | uint64_t(u(a.w)) << 32;
+        const uint64_t runs = uint64_t(u(b.x)) | uint64_t(u(b.y)) << 32;
+        const uint32_t lr = u(b.z);
+        h.seg = arena + seg;
+        h.dst = (dst & KMX_PSB_TMP) ? tmp + (dst & ~KMX_PSB_TMP) : out + dst;
+        h.runs = as_global(reinterpret_cast<const uint32_t*>(runs));
+        h.c_len = lr & 0xFFFFu; h.Rc = lr >> 16;
+        h.base = u(b.w);
+        return h;
+    };
+    u32x4 v[PF];
+    uint32_t bv = 0;
+    // (four times the thread's number, made opaque where it is used: every bound and address of the loop below derives from it, and
+    //  the compiler would otherwise keep two dozen of them in registers across the merge — the spills that follow are reloaded
+    //  through the same counter the prefetched positions arrive on, i.e. they wait for the prefetch)
+    auto tq4 = [&] { uint32_t x = tid * 4; asm volatile("" : "+v"(x)); return x; };
+    // a chunk's positions and run boundaries, into registers.  Every thread inside the chunk asks for a whole quad, the one at
+    // the chunk's end too (the arena is padded: up to three positions of whatever follows the chunk come along and are
+    // replaced by sentinels when the quad is staged) — a branch for that thread with loads of its own would put a wait for
+    // ALL of the wave's loads into this place, which is exactly what must not wait.
+    auto ask = [&](const Hdr& h) {
+        const uint32_t tq = tq4();
+        const int32_t left = int32_t(h.c_len) - int32_t(tq);       // positions of the chunk at and behind this thread's first quad
+        const uint32_t* __restrict__ at = h.seg + tq;
+#pragma unroll
+        for (uint32_t u = 0; u < PF; ++u)
+            if (left > int32_t(u * THREADS * 4)) v[u] = *reinterpret_cast<const u32x4_a4*>(at + u * THREADS * 4);
+        if (tid <= h.Rc) bv = h.runs[tid];
+    };
+    Hdr cur = header(recs[2 * j], recs[2 * j + 1]);
+    u32x4 na = {0, 0, 0, 0}, nb = {0, 0, 0, 0};                      // the record of item j + G, in flight
+    if (j + G < n_items) { na = recs[2 * (j + G)]; nb = recs[2 * (j + G) + 1]; }
+    ask(cur);
+    KMX_MARK(3);
+    for (;;) {
+        {
+            const uint32_t tq = tq4();
+            const int32_t left = int32_t(cur.c_len) - int32_t(tq);
+            u32x4 late[QPT - PF + 1];                              // (the quads that are not prefetched: chunks beyond PF * 4 * THREADS positions)
+#pragma unroll
+            for (uint32_t u = PF; u < QPT; ++u)
+                if (left > int32_t(u * THREADS * 4)) late[u - PF] = *reinterpret_cast<const u32x4_a4*>(cur.seg + tq + u * THREADS * 4);
+            uint32_t* __restrict__ to = sbuf + tq;
+#pragma unroll
+            for (uint32_t u = 0; u < QPT; ++u) {
+                const int32_t l = left - int32_t(u * THREADS * 4);
+                if (l > 0) {
+                    u32x4 w = u < PF ? v[u < PF ? u : 0] : late[u < PF ? 0 : u - PF];
+                    w.y = l > 1 ? w.y : 0xFFFFFFFFu;               // (up to three sentinels behind the chunk: inside the buffer's slack)
+                    w.z = l > 2 ? w.z : 0xFFFFFFFFu;
+                    w.w = l > 3 ? w.w : 0xFFFFFFFFu;
+                    *reinterpret_cast<u32x4*>(to + u * THREADS * 4) = w;
+                }
+            }
+        }
+        if (tid <= cur.Rc) bnd[tid] = bv <= cur.base ? 0u : min(bv - cur.base, cur.c_len);
+        __syncthreads();
+        KMX_MARK(4);                                               // staging (the wait for the chunk's loads included)
+        const bool more = j + G < n_items;                         // block-uniform
+        Hdr nxt = cur;
+        if (more) {
+            nxt = header(na, nb);
+            ask(nxt);
+            if (j + 2 * G < n_items) { na = recs[2 * (j + 2 * G)]; nb = recs[2 * (j + 2 * G) + 1]; }
+        }
+        constexpr uint32_t CH = THREADS * Shape::CPT;                                     // chunks of a round
+        const uint32_t E = max(3u, ((cur.c_len + (CH - (cur.Rc + 1) / 2) - 1) / (CH - (cur.Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
+#ifdef KMX_PHASE_TIMING
+        merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, cur.Rc, cur.c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); }, kmx_timing);
+        kmx_t0 = clock64();
+#else
+        merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, cur.Rc, cur.c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+#endif
+        // copy-out in two halves (the next chunk's positions occupy most of the registers already).  A thread's quad is the four
+        // positions of one 16-BYTE-ALIGNED place in global memory — the chunk's destination is aligned to a position, not to a quad,
+        // and a 16-byte store that straddles quads moves at a fraction of the rate (tools/probe_phases.py: 21 K cycles for 98 KB)
+        {
+            const uint32_t tq = tq4();
+            const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(cur.dst) >> 2) & 3u;       // positions the destination is behind a quad's start
+            const int32_t first = int32_t(tq) - int32_t(mis);          // this thread's first position (negative: in front of the chunk)
+            const int32_t len = int32_t(cur.c_len);
+            const uint32_t* __restrict__ from = sbuf + first;
+            uint32_t* __restrict__ to = cur.dst + first;
+            constexpr uint32_t NQ = QPT + 1;                           // (the shift can push the last positions into one more round of quads)
+#pragma unroll
+            for (uint32_t h0 = 0; h0 < NQ; h0 += (NQ + 1) / 2) {
+                u32x4 w[(NQ + 1) / 2];
+#pragma unroll
+                for (uint32_t u = 0; u < (NQ + 1) / 2; ++u) {
+                    if (h0 + u < NQ) {
+                        const int32_t e = first + int32_t((h0 + u) * THREADS * 4);
+                        const uint32_t* f = from + (h0 + u) * THREADS * 4;
+                        if (e + 3 >= 0 && e < len) {
+                            w[u].x = e >= 0 ? f[0] : 0u;
+                            w[u].y = (e + 1 >= 0 && e + 1 < len) ? f[1] : 0u;
+                            w[u].z = (e + 2 >= 0 && e + 2 < len) ? f[2] : 0u;
+                            w[u].w = e + 3 < len ? f[3] : 0u;
+                        }
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < (NQ + 1) / 2; ++u) {
+                    if (h0 + u < NQ) {
+                        const int32_t e = first + int32_t((h0 + u) * THREADS * 4);
+                        uint32_t* __restrict__ o = to + (h0 + u) * THREADS * 4;
+                        if (e >= 0 && e + 3 < len) {
+                            *reinterpret_cast<u32x4*>(o) = w[u];           // 16-byte aligned
+                        } else if (e + 3 >= 0 && e < len) {
+                            if (e >= 0) o[0] = w[u].x;
+                            if (e + 1 >= 0 && e + 1 < len) o[1] = w[u].y;
+                            if (e + 2 >= 0 && e + 2 < len) o[2] = w[u].z;
+                            if (e + 3 < len) o[3] = w[u].w;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();                                           // the buffer is the next chunk's
+        KMX_MARK(5);                                               // copy-out
+        if (!more) break;
+        cur = nxt;
+        j += G;
+    }
+}
+
+// The items the merge does not take (more than RUNS runs in a chunk: distribution sort / bitonic network), from the back of the
+// item array.
+template <int THREADS, int CAP, int RUNS>
+__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const KmxIndexDev* __restrict__ ix, const PsbItem* __restrict__ items, uint64_t cap_items,
+                                                                const unsigned long long* __restrict__ n_items_p,
+                                                                const uint32_t* __restrict__ arena, uint32_t* __restrict__ out,
+                                                                uint32_t* __restrict__ tmp)
+{
+    typedef PsbShape<THREADS, CAP, RUNS> Shape;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS + the distribution sort's counters
+    __shared__ uint32_t bnd[RUNS + 1];
+    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];
+    const uint64_t n_items = min((uint64_t)*n_items_p, cap_items);
+    for (uint64_t j = blockIdx.x; j < n_items; j += gridDim.x) {
+        const PsbItem it = items[cap_items - 1 - j];
+        uint32_t* dst = (it.dst & KMX_PSB_TMP) ? tmp + (it.dst & ~KMX_PSB_TMP) : out + it.dst;
+        const uint32_t c_len = it.len_runs & 0xFFFFu;
+        // (the run count of such a chunk is only known to be beyond RUNS: the record holds min(runs, 0xFFFF))
+        psb_chunk<THREADS, CAP, RUNS, false>(sbuf, bnd, ptab, arena + it.seg, dst, as_global(it.runs), it.base, c_len, it.len_runs >> 16, ix->n, threadIdx.x);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// BANDS.  A slice beyond the 256-thread shape whose runs are few (<= KMX_BAND_RUNS) is cut by VALUE, not by place: band s of S holds
+// the positions in [s n / S, (s + 1) n / S) of every run — about len / S of them when the k-mers of the slice occur all over the
+// text — so that the bands of a slice are independent merges whose outputs, one behind the other, ARE the sorted slice: no
+// chunk of 32768 positions that owns a CU's LDS alone (its loads and stores overlap nothing: half the time of a 24 K slice),
+// no merge passes behind the chunks of a longer slice.  A band is a 256-thread block's work (33 KB of LDS, four blocks per
+// CU: one block's gather and copy-out run under the others' rounds).
+//   k_prefix_bands       a wave per slice: where every run crosses every threshold (interpolation + galloping + halving search
+//                        in the arena), the table of these cuts, one PsbBand per band — or, when some band would exceed
+//                        KMX_PSORT_MID_CAP positions (a text whose occurrences cluster), nothing: the slice stays with the chunks
+//   k_prefix_merge_band  a block per band: gathers the R run pieces into LDS, merge_runs_lds, leaves coalesced
+// ---------------------------------------------------------------------------
+#define KMX_BAND 6144              // positions per band aimed at (a band takes up to KMX_PSORT_MID_CAP: a third of slack for uneven texts)
+#define KMX_BAND_RUNS 64           // the 256-thread shape's run capacity
+#define KMX_BAND_MAX 512           // bands per slice at most (their sums live in LDS, a row per wave)
+#ifndef KMX_PSORT_BAND_MIN
+#define KMX_PSORT_BAND_MIN KMX_PSORT_BLOCK_CAP     // slices up to this length are not cut into bands
+#endif
+struct PsbBand {
+    uint64_t src0;                 // the slice's first position in the arena
+    uint64_t dst;                  // the band's first position in `out`
+    const uint32_t* runs;          // offset-table entries of the slice's runs (n_runs + 1 of them)
+    uint32_t cuts_at;              // row s of the slice's cut table (n_runs entries; row s + 1 follows it)
+    uint32_t len_runs;             // positions in the band (16 bits) | runs << 16
+};
+static_assert(sizeof(PsbBand) == 32, "one record = two 16-byte loads");
+
+// lower bound of `thr` in the ascending run A[0, n) of text positions (first index whose entry is not below thr): first probe
+// where a text with evenly spread occurrences would have it, galloping from there, halving inside the bracket
+__device__ __forceinline__ uint32_t band_cut(const KMX_GLOBAL uint32_t* A, uint32_t n, uint32_t thr, uint64_t n_text)
+{
+    if (n == 0) return 0;
+    uint32_t lo = 0, hi = n;                                                              // the answer is in [lo, hi]
+    uint32_t g = uint32_t(min(uint64_t(n - 1), (uint64_t(thr) * n) / n_text));
+    uint32_t step = 1;
+    if (A[g] < thr) {
+        lo = g + 1;
+        while (lo < hi) {
+            const uint32_t p = min(lo + step - 1, hi - 1);
+            if (A[p] < thr) { lo = p + 1; step <<= 1; } else { hi = p; break; }
+        }
+    } else {
+        hi = g;
+        while (lo < hi) {
+            const uint32_t p = hi - min(step, hi - lo);
+            if (A[p] < thr) { lo = p + 1; break; } else { hi = p; step <<= 1; }
+        }
+    }
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (A[mid] < thr) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_bands(const KmxIndexDev* __restrict__ ix, const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                            uint64_t n_prefix, const uint64_t* __restrict__ hit_off, const uint32_t* __restrict__ arena,
+                                                            uint32_t* __restrict__ banded, PsbBand* __restrict__ bands, uint64_t cap_bands,
+                                                            uint32_t* __restrict__ cuts, uint64_t cap_cuts, unsigned long long* __restrict__ used)
+{
+    __shared__ uint32_t sums[KMX_BLOCK / KMX_WAVE][KMX_BAND_MAX + 1];                     // sums[s] = positions of the slice below threshold s
+    const uint32_t lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
+    const uint64_t i = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    if (i >= n_prefix) return;                                                            // (wave-uniform, like everything about the slice)
+    auto wsync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    const uint32_t q = d.prefix_list[i];
+    const uint32_t R = d.c0[q];
+    const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    const uint32_t S = (len + KMX_BAND - 1) / KMX_BAND;
+    auto leave = [&] { if (lane == 0) banded[i] = 0; };
+    // (a slice of one chunk stays a chunk: measured, 24 K positions of 16 runs take a 1024-thread block 5.5 ms per 5e4 slices and their
+    //  four bands 5.2 + 1.2 for the cuts — the rounds, not the memory phases, are what both wait for; what the bands save is the
+    //  merge passes behind the chunks of a longer slice: 98 K positions of 64 runs 10.1 -> 7.0 ms per 1e4 slices)
+    if (len <= KMX_PSORT_BAND_MIN || R < 2 || R > KMX_BAND_RUNS || S > KMX_BAND_MAX) { leave(); return; }
+    // the slice's cut table: rows 0 .. S of R entries (row 0: zeros, row S: the runs' lengths)
+    unsigned long long at = 0;
+    if (lane == 0) at = atomicAdd(&used[1], (unsigned long long)(S + 1) * R);
+    at = __shfl(at, 0);
+    if (at + uint64_t(S + 1) * R > cap_cuts) { leave(); return; }
+    uint32_t* __restrict__ tab = cuts + at;
+    const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);       // R + 1 run boundaries
+    const uint32_t offs0 = offs[0];
+    const uint64_t src0 = d.src[q] & ~SRC_FLAGS, n_text = ix->n;
+    const KMX_GLOBAL uint32_t* seg = as_global(arena) + src0;
+    for (uint32_t s = lane; s <= S; s += KMX_WAVE) sums[wv][s] = s == S ? len : 0u;
+    for (uint32_t r = lane; r < R; r += KMX_WAVE) { tab[r] = 0; tab[S * R + r] = offs[r + 1] - offs[r]; }
+    wsync();
+    for (uint32_t p = lane; p < (S - 1) * R; p += KMX_WAVE) {
+        const uint32_t s = 1 + p / R, r = p % R;
+        const uint32_t r_at = offs[r] - offs0, r_len = offs[r + 1] - offs[r];
+        const uint32_t c = band_cut(seg + r_at, r_len, uint32_t((uint64_t(s) * n_text) / S), n_text);
+        tab[s * R + r] = c;
+        atomicAdd(&sums[wv][s], c);
+    }
+    wsync();
+    bool fits = true;
+    for (uint32_t s = lane; s < S; s += KMX_WAVE) fits &= sums[wv][s + 1] - sums[wv][s] <= KMX_PSORT_MID_CAP;
+    if (!__all(fits)) { leave(); return; }                                                // occurrences cluster: the chunks take the slice
+    unsigned long long b_at = 0;
+    if (lane == 0) b_at = atomicAdd(&used[0], (unsigned long long)S);
+    b_at = __shfl(b_at, 0);
+    if (b_at + S > cap_bands) { leave(); return; }                                        // (cannot happen: the caller's bound is exact)
+    const uint64_t dst0 = hit_off[q];
+    for (uint32_t s = lane; s < S; s += KMX_WAVE) {
+        PsbBand b;
+        b.src0 = src0;
+        b.dst = dst0 + sums[wv][s];
+        b.runs = (const uint32_t*)offs;
+        b.cuts_at = uint32_t(at + uint64_t(s) * R);
+        b.len_runs = (sums[wv][s + 1] - sums[wv][s]) | (R << 16);
+        bands[b_at + s] = b;
+    }
+    if (lane == 0) banded[i] = 1;
+}
+
+template <int THREADS, int CAP, int RUNS>
+__global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_band(const PsbBand* __restrict__ bands, uint64_t cap_bands,
+                                                                const unsigned long long* __restrict__ n_bands_p, const uint32_t* __restrict__ cuts,
+                                                                const uint32_t* __restrict__ arena, uint32_t* __restrict__ out)
+{
+    typedef PsbShape<THREADS, CAP, RUNS> Shape;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
+    __shared__ uint32_t bnd[RUNS + 1];
+    __shared__ uint32_t piece[RUNS];                               // where run r's piece of the band starts, in the slice
+    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
+    static_assert(RUNS <= KMX_WAVE, "one wave scans the pieces' lengths");
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_bands = min((uint64_t)*n_bands_p, cap_bands);
+    for (uint64_t j = blockIdx.x; j < n_bands; j += gridDim.x) {
+        const PsbBand b = bands[j];
+        const uint32_t len = __builtin_amdgcn_readfirstlane(b.len_runs & 0xFFFFu), R = __builtin_amdgcn_readfirstlane(b.len_runs >> 16);
+        if (tid < KMX_WAVE) {
+            uint32_t n_r = 0, at = 0;
+            if (tid < R) {
+                const KMX_GLOBAL uint32_t* runs = as_global(b.runs);
+                const uint32_t lo = cuts[b.cuts_at + tid], hi = cuts[b.cuts_at + R + tid];
+                n_r = hi - lo;
+                at = (runs[tid] - runs[0]) + lo;
+            }
+            uint32_t inc = n_r;
+#pragma unroll
+            for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
+                const uint32_t t = __shfl_up(inc, o);
+                if (tid >= o) inc += t;
+            }
+            if (tid < R) { bnd[tid + 1] = inc; piece[tid] = at; }
+            if (tid == 0) bnd[0] = 0;
+        }
+        __syncthreads();
+        {
+            // the gather: slot t of the band is entry t - bnd[r] of run r's piece (r advances with t: a thread's slots are THREADS apart)
+            const uint32_t* __restrict__ seg = arena + b.src0;
+            constexpr uint32_t PT = CAP / THREADS, GRP = 8;       // eight loads in flight per thread, then their eight LDS stores
+            static_assert(PT % GRP == 0, "whole groups");
+            uint32_t r = 0;
+#pragma unroll 1
+            for (uint32_t u0 = 0; u0 < PT && u0 * THREADS < len; u0 += GRP) {
+                uint32_t val[GRP];
+                const uint32_t t0 = u0 * THREADS + tid;
+#pragma unroll
+                for (uint32_t u = 0; u < GRP; ++u) {
+                    const uint32_t t = t0 + u * THREADS;
+                    if (t < len) {
+                        while (t >= bnd[r + 1]) ++r;
+                        val[u] = seg[piece[r] + (t - bnd[r])];
+                    }
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < GRP; ++u) {
+                    const uint32_t t = t0 + u * THREADS;
+                    if (t < len) sbuf[t] = val[u];
+                }
+            }
+        }
+        __syncthreads();
+        constexpr uint32_t CH = THREADS * Shape::CPT;                                     // chunks of a round
+        const uint32_t E = max(3u, ((len + (CH - (R + 1) / 2) - 1) / (CH - (R + 1) / 2)) | 1u);   // (odd: LDS banks)
+        merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, R, len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+        {
+            constexpr uint32_t QPT = (CAP / 4 + THREADS - 1) / THREADS;
+            uint32_t* __restrict__ dst = out + b.dst;
+            u32x4 v[QPT];
+#pragma unroll
+            for (uint32_t u = 0; u < QPT; ++u) {
+                const uint32_t t = (u * THREADS + tid) * 4;
+                if (t < len) v[u] = *reinterpret_cast<const u32x4*>(sbuf + t);
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < QPT; ++u) {
+                const uint32_t t = (u * THREADS + tid) * 4;
+                if (t + 3 < len) {
+                    *reinterpret_cast<u32x4_a4*>(dst + t) = v[u];
+                } else if (t < len) {
+                    dst[t] = v[u].x;
+                    if (t + 1 < len) dst[t + 1] = v[u].y;
+                    if (t + 2 < len) dst[t + 2] = v[u].z;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+uint64_t prefix_item_bytes() { return sizeof(PsbItem); }
+uint64_t prefix_band_target() { return KMX_BAND; }
+uint64_t prefix_band_runs() { return KMX_BAND_RUNS; }
+
+// The slices beyond the 256-thread shape that can be cut into bands (few runs, occurrences spread over the text): cut tables and
+// band records, banded[i] = 1 for them (0 for every other listed slice).  bands: room for cap_bands records of
+// prefix_item_bytes() each, cap_bands >= 6 per listed slice beyond KMX_PSORT_MID_CAP + (positions of the slices beyond
+// KMX_PSORT_BLOCK_CAP) / prefix_band_target(); cuts: cap_cuts words (a slice that finds no room stays with the chunks);
+// used: two zeroed device counters (KMX_CTR_PSB_BANDS, KMX_CTR_PSB_CUTS)
+void launch_prefix_bands(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off,
+                         const uint32_t* arena, uint32_t* banded, void* bands, uint64_t cap_bands, uint32_t* cuts, uint64_t cap_cuts,
+                         unsigned long long* used)
+{
+    hipLaunchKernelGGL(k_prefix_bands, dim3(blocks_for(n_prefix * KMX_WAVE, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, arena,
+                       banded, static_cast<PsbBand*>(bands), cap_bands, cuts, cap_cuts, used);
+}
+
+// n_mid of the n_prefix listed queries have slices of at most KMX_PSORT_MID_CAP positions; banded / bands / cuts / n_bands: what
+// launch_prefix_bands left; items: room for cap_items records (>= one per listed slice beyond KMX_PSORT_MID_CAP + one per
+// KMX_PSORT_BLOCK_CAP positions of the slices longer than that); n_items: two zeroed counters
 void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
-                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp)
+                              const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp,
+                              void* items, uint64_t cap_items, unsigned long long* n_items, const uint32_t* banded, const void* bands, uint64_t cap_bands,
+                              const uint32_t* cuts, const unsigned long long* n_bands, unsigned long long* dbg)
 {
     if (n_mid) {
-        auto fn = k_prefix_sort_block<256, KMX_PSORT_MID_CAP, 64, true>;
+        auto fn = k_prefix_sort_block<256, KMX_PSORT_MID_CAP, 64>;
         const size_t lds = size_t(PsbMid::WORDS) * 4;
         const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 16);
-        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(256), lds, s, ix, qoff, d, n_prefix, hit_off, arena, out, tile_off, tmp);
+        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(256), lds, s, ix, qoff, d, n_prefix, hit_off, arena, out);
     }
     if (n_prefix > n_mid) {
-        auto fn = k_prefix_sort_block<1024, KMX_PSORT_BLOCK_CAP, 128, false>;
-        const size_t lds = size_t(PsbBig::WORDS) * 4;
-        allow_big_lds(reinterpret_cast<const void*>(fn), lds, 0);
-        const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 4);
-        const unsigned int ychunks = blocks >= 256 ? 1u : std::min(16u, 1024u / std::max(blocks, 1u));   // few queries: spread their chunks
-        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, ychunks ? ychunks : 1), dim3(1024), lds, s, ix, qoff, d, n_prefix, hit_off, arena, out,
-                           tile_off, tmp);
+        {
+            auto fn = k_prefix_merge_band<256, KMX_PSORT_MID_CAP, KMX_BAND_RUNS>;
+            const size_t lds = size_t(PsbMid::WORDS) * 4;
+            const unsigned int blocks = (unsigned int)std::min<uint64_t>(cap_bands, 256 * 16);
+            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(256), lds, s, static_cast<const PsbBand*>(bands), cap_bands, n_bands, cuts, arena, out);
+        }
+        PsbItem* it = static_cast<PsbItem*>(items);
+        hipLaunchKernelGGL((k_prefix_items<KMX_PSORT_BLOCK_CAP, 128>), dim3(blocks_for(n_prefix * KMX_WAVE, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qoff, d,
+                           n_prefix, hit_off, banded, tile_off, it, cap_items, n_items);
+        const unsigned int blocks = (unsigned int)std::min<uint64_t>(cap_items, 256);     // one per CU: they are pipelines, not a queue
+        {
+            auto fn = k_prefix_merge_block<1024, KMX_PSORT_BLOCK_CAP, 128>;
+            const size_t lds = size_t(PsbBig::WORDS) * 4;
+            allow_big_lds(reinterpret_cast<const void*>(fn), lds, 0);
+            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(1024), lds, s, it, n_items, arena, out, tmp, dbg);
+        }
+        {
+            auto fn = k_prefix_sort_items<1024, KMX_PSORT_BLOCK_CAP, 128>;
+            const size_t lds = size_t(PsbBig::WORDS + KMX_PBK_NB / 2) * 4;        // (+ the counters of the distribution sort)
+            allow_big_lds(reinterpret_cast<const void*>(fn), lds, 2);
+            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(1024), lds, s, ix, it, cap_items, n_items + 1, arena, out, tmp);
+        }
     }
 }
 

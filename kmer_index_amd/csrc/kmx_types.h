@@ -213,7 +213,11 @@ enum {
     KMX_CTR_PREFIX_PLAIN = 0,  // PREFIX queries answered by ONE list (nothing to sort: on no work list)
     KMX_CTR_STITCH_SHORT = 16, // two-part STITCH queries whose shorter bucket has at most KMX_VSHORT entries (listed in QueryDesc::short_list)
     KMX_CTR_LONG = 17,         // single-k queries of more than KMX_LONG_PARTS parts (k_lookup_long takes them when the batch before had some)
-    KMX_CTR_COUNT = 20
+    KMX_CTR_PSB_MERGE = 18,    // chunks of the longer PREFIX slices listed for k_prefix_merge_block (k_prefix_items counts; KMX_CTR_PSB_OTHER follows it)
+    KMX_CTR_PSB_OTHER = 19,    // ... and for k_prefix_sort_items (more runs than the merge takes)
+    KMX_CTR_PSB_BANDS = 20,    // bands of the PREFIX slices k_prefix_bands cut (k_prefix_merge_band's work; KMX_CTR_PSB_CUTS follows it)
+    KMX_CTR_PSB_CUTS = 21,     // words of cut tables handed out
+    KMX_CTR_COUNT = 24
 };
 #define KMX_LONG_PARTS 256      // parts beyond which a query's probes are spread over the lanes of a wave instead of walked by one lane
                                 // (measured: 100 parts — 1000 letters on k = 10 — are faster walked, 0.76 against 2.5 ms per 1e5 reads: a

@@ -850,6 +850,39 @@ def test_prefix_slices_whose_positions_cluster(engine, orc):
         idx.close()
 
 
+def test_prefix_slices_cut_into_bands(engine, orc):
+    """Slices beyond a chunk (32768 positions) of at most 64 runs are cut into value bands (k_prefix_bands / k_prefix_merge_band): on a
+    text whose k-mers occur all over it every band fits a 256-thread block and no merge pass runs over the slice; where the occurrences
+    of a prefix crowd into a part of the text (here: the first quarter is written in two letters, the rest in the other two) a band
+    would overflow and the slice stays with the chunks + merge passes.  Both equal the oracle, and the two kinds share one batch."""
+    rng = np.random.default_rng(23)
+    n = 3_000_000
+    even = rng.integers(0, 4, n).astype(np.uint8)
+    skew = np.concatenate([rng.integers(0, 2, n // 4), rng.integers(2, 4, n - n // 4)]).astype(np.uint8)
+    for text, sigma, ks in ((even, 4, [6]), (skew, 4, [6]), (even % 2, 2, [12])):
+        idx = engine.Index(text, sigma, ks, prefix_levels=-1)
+        oidx = orc.Index(text, sigma, ks)
+        k = ks[0]
+        # m = k - 3 on 4 letters: 64 runs, n / 64 = 46.9 K positions (8 bands); k - 2: 16 runs of 11.7 K (one chunk); on 2 letters
+        # m = k - 6: 64 runs, 46.9 K positions; m = k - 5: 32 runs, 23.4 K; m = k - 4: 16 runs, 11.7 K
+        lens = (k - 3, k - 2, k - 1) if sigma == 4 else (k - 6, k - 5, k - 4, k - 2)
+        qs = [text[s0:s0 + m].copy() for m in lens for s0 in range(1000, 1000 + 53 * 24, 53)]
+        qs += [rng.integers(0, sigma, m).astype(np.uint8) for m in lens for _ in range(8)]
+        qs += [text[n - m:].copy() for m in lens]                                               # with last-kmer positions
+        qranks, qoff = pack(qs)
+        idx.stats_enable(True)
+        r = idx.search(qranks, qoff)
+        ho, pos, st, kd = r.host()
+        o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=8)
+        assert np.array_equal(st, o_st.astype(np.uint8))
+        assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
+        assert int(np.diff(ho).max()) > 40_000
+        assert idx.stats()["k_prefix_bands"]["launches"]
+        ho2, pos2, _, _ = idx.search(qranks, qoff, result=r).host()                              # the same handle again (buffers, counters)
+        assert np.array_equal(ho2, o_off) and np.array_equal(pos2, o_pos)
+        idx.close()
+
+
 @pytest.mark.parametrize("sigma,ks", [(4, [16]), (4, [14, 20, 31]), (2, [40, 63]), (20, [7, 12]), (5, [12, 4])])
 def test_sorted_pairs_device_build_equals_host_flatten(engine, orc, sigma, ks, tmp_path):
     """Elements whose key space is beyond the histogram path (sigma^k > 2^26) are built on the device from sorted
