@@ -3083,33 +3083,54 @@ __device__ __forceinline__ void merge_chunks(const KMX_LDS uint32_t* (&pa)[C], c
 #else
 #define KMX_MARK(word) do { } while (0)
 #endif
-template <int EMAX, int NT, int TSTRIDE, int C, typename Sync>
-__device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R, uint32_t len,
-                                               uint32_t E, uint32_t rcp, uint32_t tid, Sync sync, unsigned long long* kmx_timing = nullptr)
-{
+// MergeRuns: the rounds one at a time — begin(), then round<true>() for the first and round<false>() for the others while more();
+// merge_runs_lds below is that loop.  A caller that wants memory operations of its own to run under the rounds
+// (k_prefix_merge_block) calls the rounds itself and passes two callables per round: b0 runs in front of the round's searches, b1 in
+// front of its merge steps (every thread calls them; straight-line places).
+struct MergeNoHook { __device__ __forceinline__ void operator()() const {} };
+template <int EMAX, int NT, int TSTRIDE, int C>
+struct MergeRuns {
+    static constexpr bool PRETAB = TSTRIDE > 0;
+    static constexpr uint32_t KMX_PM_TSTRIDE = TSTRIDE;
+    KMX_LDS uint32_t* lb;
+    const KMX_LDS uint32_t* lbnd;
+    KMX_LDS uint32_t* lpt0;
+    uint32_t R, E, rcp, tid, lane;
+    uint32_t w = 1, ngroups, rnd = 0;
+    unsigned long long* kmx_timing;
 #ifdef KMX_PHASE_TIMING
-    long long kmx_t0 = clock64();
+    long long kmx_t0;
 #endif
-    constexpr bool PRETAB = TSTRIDE > 0;
-    constexpr uint32_t KMX_PM_TSTRIDE = TSTRIDE;
-    KMX_LDS uint32_t* lb = (KMX_LDS uint32_t*)buf;
-    const KMX_LDS uint32_t* lbnd = (const KMX_LDS uint32_t*)bnd;
-    KMX_LDS uint32_t* lpt0 = (KMX_LDS uint32_t*)ptab;
-    const uint32_t lane = tid & (KMX_WAVE - 1);
-    if (PRETAB) {
-        uint32_t r = tid / KMX_WAVE, w = 1u << r;
-        for (; w < R; r += NT / KMX_WAVE, w <<= NT / KMX_WAVE) {
-            const uint32_t ngroups = (R + w - 1) / w;
-            merge_pair_table(lpt0 + r * KMX_PM_TSTRIDE, lbnd, R, w, (ngroups + 1) >> 1, E, rcp, lane);
-        }
-        sync();
+    __device__ __forceinline__ MergeRuns(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R_, uint32_t E_, uint32_t rcp_, uint32_t tid_,
+                                         unsigned long long* timing)
+        : lb((KMX_LDS uint32_t*)buf), lbnd((const KMX_LDS uint32_t*)bnd), lpt0((KMX_LDS uint32_t*)ptab), R(R_), E(E_), rcp(rcp_), tid(tid_),
+          lane(tid_ & (KMX_WAVE - 1)), ngroups(R_), kmx_timing(timing)
+    {
+#ifdef KMX_PHASE_TIMING
+        kmx_t0 = clock64();
+#endif
     }
-    KMX_MARK(6);
-    uint32_t w = 1, ngroups = R, rnd = 0;
-    bool first = true;
-    while (ngroups > 1) {
+    __device__ __forceinline__ bool more() const { return ngroups > 1; }
+    template <typename Sync>
+    __device__ __forceinline__ void begin(Sync sync)
+    {
+        if (PRETAB) {
+            uint32_t r = tid / KMX_WAVE, w2 = 1u << r;
+            for (; w2 < R; r += NT / KMX_WAVE, w2 <<= NT / KMX_WAVE) {
+                const uint32_t ng = (R + w2 - 1) / w2;
+                merge_pair_table(lpt0 + r * KMX_PM_TSTRIDE, lbnd, R, w2, (ng + 1) >> 1, E, rcp, lane);
+            }
+            sync();
+        }
+        KMX_MARK(6);
+    }
+    template <bool FIRST, typename Sync, typename B0, typename B1>
+    __device__ __forceinline__ void round(Sync sync, B0 b0, B1 b1)
+    {
+        constexpr bool first = FIRST;
         const uint32_t npairs = (ngroups + 1) >> 1;
         KMX_LDS uint32_t* lpt = PRETAB ? lpt0 + rnd * KMX_PM_TSTRIDE : lpt0;
+        b0();
         if (!PRETAB) {
             if (tid < KMX_WAVE) merge_pair_table(lpt, lbnd, R, w, npairs, E, rcp, lane);
             sync();
@@ -3150,13 +3171,12 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
             pA[u] = lb + (first ? s[u] : s[u] + 2 * p[u]);
             pB[u] = lb + (first ? mi[u] : mi[u] + 2 * p[u] + 1);
         }
-        // where every chunk's diagonal crosses the merge path: `steps` halving steps, the C searches in lockstep (branch-free: a
-        // candidate beyond the bracket reads a clamped entry and is refused)
+        // where every chunk's diagonal crosses the merge path: `steps` halving steps, the C searches in lockstep
         uint32_t lo[C];
         {
             // (every thread halves its OWN bracket: the probes of a wave's threads then fall wherever their diagonals put them.  With
             //  common strides — lo + 2^k for everybody — the probes of a step were a multiple of 2^k apart: one LDS bank for the
-            //  whole wave in the steps of 32 words and more, a third of the pipe's rate in this phase)
+            //  whole wave in the steps of 32 words and more)
             uint32_t hi[C];
 #pragma unroll
             for (int u = 0; u < C; ++u) { lo[u] = dg[u] > nb[u] ? dg[u] - nb[u] : 0u; hi[u] = min(dg[u], na[u]); }
@@ -3177,8 +3197,8 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
             }
         }
         KMX_MARK(7);                                               // pair lookup + merge-path searches
-        // (the two kinds of round as two copies of "merge, barrier, write back": one set of registers each)
-        auto round = [&](auto checked) {
+        b1();
+        {
             uint32_t x[C][EMAX];
             const KMX_LDS uint32_t* qa[C];
             const KMX_LDS uint32_t* qb[C];
@@ -3186,7 +3206,7 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
             const KMX_LDS uint32_t* eb[C];
 #pragma unroll
             for (int u = 0; u < C; ++u) { qa[u] = pA[u] + lo[u]; qb[u] = pB[u] + (dg[u] - lo[u]); ea[u] = lb + mi[u]; eb[u] = lb + e[u]; }
-            merge_chunks<EMAX, decltype(checked)::value, C>(qa, qb, ea, eb, E, x);
+            merge_chunks<EMAX, FIRST, C>(qa, qb, ea, eb, E, x);    // (the first round's runs lie side by side: its reads are checked against their ends)
             KMX_MARK(8);                                           // the E merge steps
             sync();                                                // every read of the round is done
             KMX_MARK(9);                                           // barrier wait
@@ -3210,9 +3230,7 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
                         }
                 }
             }
-        };
-        if (first) round(std::true_type{});
-        else round(std::false_type{});
+        }
         if (tid < npairs) lb[lpt[4 * tid + 2] + tid] = KMX_PM_SENT;   // the cell behind every merged group
         if (PRETAB && npairs > 1) {
             // the next round's unpaired group (if any) merges with an empty partner: its sentinel, in the layout just written
@@ -3224,9 +3242,18 @@ __device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bn
         KMX_MARK(10);                                              // write back + sentinels + barrier
         w <<= 1;
         ngroups = npairs;
-        first = false;
         ++rnd;
     }
+};
+
+template <int EMAX, int NT, int TSTRIDE, int C, typename Sync>
+__device__ __forceinline__ void merge_runs_lds(uint32_t* buf, const uint32_t* bnd, uint32_t* ptab, uint32_t R, uint32_t len,
+                                               uint32_t E, uint32_t rcp, uint32_t tid, Sync sync, unsigned long long* kmx_timing = nullptr)
+{
+    MergeRuns<EMAX, NT, TSTRIDE, C> m(buf, bnd, ptab, R, E, rcp, tid, kmx_timing);
+    m.begin(sync);
+    if (m.more()) m.template round<true>(sync, MergeNoHook(), MergeNoHook());
+    while (m.more()) m.template round<false>(sync, MergeNoHook(), MergeNoHook());
 }
 
 // ---------------------------------------------------------------------------
@@ -4073,13 +4100,14 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_items(const KmxIndexDev* _
     }
 }
 
-// The items the merge takes, one block per CU walking its share of them as a PIPELINE: while chunk j is merged in LDS, chunk
-// j + 1's positions (asked for right behind j's staging barrier) arrive in registers and item j + 2's record is on its way, and
-// j's copy-out leaves as stores nobody waits for.  A 128-KB block owns its CU alone, so nothing else overlaps its memory phases:
-// without this, loading a chunk, its header and storing it were half of the block's time with the LDS pipe idle.
-#ifndef KMX_PSB_PREFETCH
-#define KMX_PSB_PREFETCH 8     // quads of the next chunk a thread holds in registers while it merges (of CAP / 4 / THREADS: the others are
-#endif                         // asked for when the chunk is staged)
+// The items the merge takes, one block per CU walking its share of them as a PIPELINE.  A 128-KB block owns its CU alone, so nothing
+// else overlaps its memory phases, and a CU moves about 5 bytes per clock to or from memory (k_fill's rate as well): loading a
+// 98-KB chunk, its header's five dependent round trips and storing it were half of the block's time with the LDS pipe idle
+// (tools/probe_phases.py).  So a thread keeps two sets of eight quads in registers:
+//   A   the chunk in hand: its positions as they arrived, staged into LDS; after the rounds its sorted positions, read back from LDS
+//   B   while the rounds run: the PREVIOUS chunk's sorted positions, handed to memory quad by quad between the phases of the
+//       rounds (merge_runs_lds' between()), each quad's registers asked to receive the NEXT chunk's positions right behind its store
+// and the sets change places at the end; item records arrive two chunks ahead.  Nothing in the rounds waits for memory.
 template <int THREADS, int CAP, int RUNS>
 __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem* __restrict__ items, const unsigned long long* __restrict__ n_items_p,
                                                                  const uint32_t* __restrict__ arena, uint32_t* __restrict__ out,
@@ -4090,7 +4118,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem
     __shared__ uint32_t bnd[RUNS + 1];
     __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
     constexpr uint32_t QPT = (CAP / 4 + THREADS - 1) / THREADS;       // quads per thread
-    constexpr uint32_t PF = KMX_PSB_PREFETCH < QPT ? KMX_PSB_PREFETCH : QPT;
+    static_assert(QPT == 8, "between() below hands out eight quads");
     const uint32_t tid = threadIdx.x;
     const uint64_t n_items = *n_items_p, G = gridDim.x;
     uint64_t j = blockIdx.x;
@@ -4114,44 +4142,50 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem
         h.base = u(b.w);
         return h;
     };
-    u32x4 v[PF];
-    uint32_t bv = 0;
-    // (four times the thread's number, made opaque where it is used: every bound and address of the loop below derives from it, and
-    //  the compiler would otherwise keep two dozen of them in registers across the merge — the spills that follow are reloaded
-    //  through the same counter the prefetched positions arrive on, i.e. they wait for the prefetch)
+    // (four times the thread's number, made opaque where it is used: every bound and address below derives from it, and the compiler
+    //  would otherwise keep two dozen of them in registers across the rounds — the spills that follow are reloaded through the same
+    //  counter the prefetched positions arrive on, i.e. they wait for the prefetch)
     auto tq4 = [&] { uint32_t x = tid * 4; asm volatile("" : "+v"(x)); return x; };
-    // a chunk's positions and run boundaries, into registers.  Every thread inside the chunk asks for a whole quad, the one at
-    // the chunk's end too (the arena is padded: up to three positions of whatever follows the chunk come along and are
-    // replaced by sentinels when the quad is staged) — a branch for that thread with loads of its own would put a wait for
-    // ALL of the wave's loads into this place, which is exactly what must not wait.
-    auto ask = [&](const Hdr& h) {
-        const uint32_t tq = tq4();
-        const int32_t left = int32_t(h.c_len) - int32_t(tq);       // positions of the chunk at and behind this thread's first quad
-        const uint32_t* __restrict__ at = h.seg + tq;
-#pragma unroll
-        for (uint32_t u = 0; u < PF; ++u)
-            if (left > int32_t(u * THREADS * 4)) v[u] = *reinterpret_cast<const u32x4_a4*>(at + u * THREADS * 4);
-        if (tid <= h.Rc) bv = h.runs[tid];
+    // quad k of a chunk into registers.  Every thread inside the chunk asks for a whole quad, the one at the chunk's end too (the
+    // arena is padded: up to three positions of whatever follows the chunk come along and are replaced by sentinels when the quad
+    // is staged) — a branch for that thread with loads of its own would put a wait for ALL of the wave's loads into this place
+    auto ask = [&](const Hdr& h, u32x4& q, uint32_t k) {
+        const uint32_t t = tq4() + k * THREADS * 4;
+        if (t < h.c_len) q = *reinterpret_cast<const u32x4_a4*>(h.seg + t);
     };
-    Hdr cur = header(recs[2 * j], recs[2 * j + 1]);
+    // quad k of a sorted chunk to where the chunk goes
+    auto give = [&](const Hdr& h, const u32x4& q, uint32_t k) {
+        const uint32_t t = tq4() + k * THREADS * 4;
+        const int32_t l = int32_t(h.c_len) - int32_t(t);
+        uint32_t* __restrict__ o = h.dst + t;
+        if (l > 3) {
+            *reinterpret_cast<u32x4_a4*>(o) = q;
+        } else if (l > 0) {
+            o[0] = q.x;
+            if (l > 1) o[1] = q.y;
+            if (l > 2) o[2] = q.z;
+        }
+    };
+    u32x4 A[QPT], B[QPT];
+    uint32_t bv = 0;
+    Hdr cur = header(recs[2 * j], recs[2 * j + 1]), prev = cur;
+    prev.c_len = 0;
     u32x4 na = {0, 0, 0, 0}, nb = {0, 0, 0, 0};                      // the record of item j + G, in flight
     if (j + G < n_items) { na = recs[2 * (j + G)]; nb = recs[2 * (j + G) + 1]; }
-    ask(cur);
+#pragma unroll
+    for (uint32_t k = 0; k < QPT; ++k) ask(cur, A[k], k);
+    if (tid <= cur.Rc) bv = cur.runs[tid];
     KMX_MARK(3);
     for (;;) {
         {
             const uint32_t tq = tq4();
             const int32_t left = int32_t(cur.c_len) - int32_t(tq);
-            u32x4 late[QPT - PF + 1];                              // (the quads that are not prefetched: chunks beyond PF * 4 * THREADS positions)
-#pragma unroll
-            for (uint32_t u = PF; u < QPT; ++u)
-                if (left > int32_t(u * THREADS * 4)) late[u - PF] = *reinterpret_cast<const u32x4_a4*>(cur.seg + tq + u * THREADS * 4);
             uint32_t* __restrict__ to = sbuf + tq;
 #pragma unroll
             for (uint32_t u = 0; u < QPT; ++u) {
                 const int32_t l = left - int32_t(u * THREADS * 4);
                 if (l > 0) {
-                    u32x4 w = u < PF ? v[u < PF ? u : 0] : late[u < PF ? 0 : u - PF];
+                    u32x4 w = A[u];
                     w.y = l > 1 ? w.y : 0xFFFFFFFFu;               // (up to three sentinels behind the chunk: inside the buffer's slack)
                     w.z = l > 2 ? w.z : 0xFFFFFFFFu;
                     w.w = l > 3 ? w.w : 0xFFFFFFFFu;
@@ -4164,66 +4198,57 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem
         KMX_MARK(4);                                               // staging (the wait for the chunk's loads included)
         const bool more = j + G < n_items;                         // block-uniform
         Hdr nxt = cur;
+        nxt.c_len = 0;
         if (more) {
             nxt = header(na, nb);
-            ask(nxt);
+            if (tid <= nxt.Rc) bv = nxt.runs[tid];
             if (j + 2 * G < n_items) { na = recs[2 * (j + 2 * G)]; nb = recs[2 * (j + 2 * G) + 1]; }
         }
+        // (no previous chunk: prev is a copy of cur with no positions; no next chunk: nxt is — so that the two steps are unconditional)
+        auto quad = [&](uint32_t k) {
+            give(prev, B[k], k);
+            ask(nxt, B[k], k);
+        };
         constexpr uint32_t CH = THREADS * Shape::CPT;                                     // chunks of a round
         const uint32_t E = max(3u, ((cur.c_len + (CH - (cur.Rc + 1) / 2) - 1) / (CH - (cur.Rc + 1) / 2)) | 1u);   // (odd: LDS banks)
+        {
+            // the first four rounds written out, each with two of B's quads at places of their own in the code (a quad's registers
+            // must be NAMED where it is stored and asked for: picked by a counter they would be copied about, and a copy of a
+            // register that a load is still on its way to waits for the load); rounds not run leave their quads for behind the loop
+            auto sync = [] { __syncthreads(); };
+            MergeRuns<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT> m(sbuf, bnd, ptab, cur.Rc, E, 0xFFFFFFFFu / E + 1, tid, kmx_timing);
+            m.begin(sync);
+            uint32_t ran = 0;                                      // (uniform)
+            if (m.more()) { m.template round<true>(sync, [&] { quad(0); }, [&] { quad(1); }); ran = 1; }
+            if (m.more()) { m.template round<false>(sync, [&] { quad(2); }, [&] { quad(3); }); ran = 2; }
+            if (m.more()) { m.template round<false>(sync, [&] { quad(4); }, [&] { quad(5); }); ran = 3; }
+            if (m.more()) { m.template round<false>(sync, [&] { quad(6); }, [&] { quad(7); }); ran = 4; }
+            while (m.more()) m.template round<false>(sync, MergeNoHook(), MergeNoHook());
 #ifdef KMX_PHASE_TIMING
-        merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, cur.Rc, cur.c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); }, kmx_timing);
-        kmx_t0 = clock64();
-#else
-        merge_runs_lds<Shape::EMAX, THREADS, Shape::TSTRIDE, Shape::CPT>(sbuf, bnd, ptab, cur.Rc, cur.c_len, E, 0xFFFFFFFFu / E + 1, tid, [] { __syncthreads(); });
+            kmx_t0 = clock64();
 #endif
-        // copy-out in two halves (the next chunk's positions occupy most of the registers already).  A thread's quad is the four
-        // positions of one 16-BYTE-ALIGNED place in global memory — the chunk's destination is aligned to a position, not to a quad,
-        // and a 16-byte store that straddles quads moves at a fraction of the rate (tools/probe_phases.py: 21 K cycles for 98 KB)
+#pragma unroll
+            for (uint32_t r = 0; r < QPT / 2; ++r)
+                if (ran <= r) { quad(2 * r); quad(2 * r + 1); }
+        }
         {
             const uint32_t tq = tq4();
-            const uint32_t mis = uint32_t(reinterpret_cast<uintptr_t>(cur.dst) >> 2) & 3u;       // positions the destination is behind a quad's start
-            const int32_t first = int32_t(tq) - int32_t(mis);          // this thread's first position (negative: in front of the chunk)
-            const int32_t len = int32_t(cur.c_len);
-            const uint32_t* __restrict__ from = sbuf + first;
-            uint32_t* __restrict__ to = cur.dst + first;
-            constexpr uint32_t NQ = QPT + 1;                           // (the shift can push the last positions into one more round of quads)
+            const int32_t left = int32_t(cur.c_len) - int32_t(tq);
+            const uint32_t* __restrict__ from = sbuf + tq;
 #pragma unroll
-            for (uint32_t h0 = 0; h0 < NQ; h0 += (NQ + 1) / 2) {
-                u32x4 w[(NQ + 1) / 2];
-#pragma unroll
-                for (uint32_t u = 0; u < (NQ + 1) / 2; ++u) {
-                    if (h0 + u < NQ) {
-                        const int32_t e = first + int32_t((h0 + u) * THREADS * 4);
-                        const uint32_t* f = from + (h0 + u) * THREADS * 4;
-                        if (e + 3 >= 0 && e < len) {
-                            w[u].x = e >= 0 ? f[0] : 0u;
-                            w[u].y = (e + 1 >= 0 && e + 1 < len) ? f[1] : 0u;
-                            w[u].z = (e + 2 >= 0 && e + 2 < len) ? f[2] : 0u;
-                            w[u].w = e + 3 < len ? f[3] : 0u;
-                        }
-                    }
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < (NQ + 1) / 2; ++u) {
-                    if (h0 + u < NQ) {
-                        const int32_t e = first + int32_t((h0 + u) * THREADS * 4);
-                        uint32_t* __restrict__ o = to + (h0 + u) * THREADS * 4;
-                        if (e >= 0 && e + 3 < len) {
-                            *reinterpret_cast<u32x4*>(o) = w[u];           // 16-byte aligned
-                        } else if (e + 3 >= 0 && e < len) {
-                            if (e >= 0) o[0] = w[u].x;
-                            if (e + 1 >= 0 && e + 1 < len) o[1] = w[u].y;
-                            if (e + 2 >= 0 && e + 2 < len) o[2] = w[u].z;
-                            if (e + 3 < len) o[3] = w[u].w;
-                        }
-                    }
-                }
-            }
+            for (uint32_t u = 0; u < QPT; ++u)
+                if (left > int32_t(u * THREADS * 4)) A[u] = *reinterpret_cast<const u32x4*>(from + u * THREADS * 4);
         }
         __syncthreads();                                           // the buffer is the next chunk's
-        KMX_MARK(5);                                               // copy-out
-        if (!more) break;
+        KMX_MARK(5);                                               // sorted chunk LDS -> registers
+        if (!more) {
+#pragma unroll
+            for (uint32_t k = 0; k < QPT; ++k) give(cur, A[k], k);
+            break;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < QPT; ++k) { const u32x4 t = A[k]; A[k] = B[k]; B[k] = t; }
+        prev = cur;
         cur = nxt;
         j += G;
     }
