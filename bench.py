@@ -415,13 +415,13 @@ def worker(args):
     # same pipeline as `value`, checked by re-reading the first 2000 queries' positions and by the hit total of a second pass
     # A query length the configs do not hold, on an index that is already built: nq_p queries of m letters (half planted),
     # the same pipeline, checked by re-reading the first 2000 queries' positions.  Sub-k lengths and long reads: informational.
-    def length_probe(index, text_, sigma_, m_, nq_p=500_000, flags_env=None):
+    def length_probe(index, text_, sigma_, m_, nq_p=500_000, flags_env=None, nv_p=2000):
         qr_p, qo_p = synth.mixed_queries(100 + m_, text_, nq_p, [m_], sigma_)
         q_p = (torch.from_numpy(qr_p).to(dev), torch.from_numpy(qo_p.view(np.int64)).to(dev), nq_p)
         el_p, res_p, st_p = run_sharded(index, max(3, args.steps // 4), 1, True, 1, q_p)
         cn = res_p[0].counts()
         ho, po, _, _ = res_p[0].host(copy=False)
-        ok = reread_ok(text_, qr_p, qo_p, ho, po, min(2000, nq_p)) and windows_complete_ok(text_, sigma_, qr_p, qo_p, ho, po, min(500, nq_p))
+        ok = reread_ok(text_, qr_p, qo_p, ho, po, min(nv_p, nq_p)) and windows_complete_ok(text_, sigma_, qr_p, qo_p, ho, po, min(nv_p // 4, nq_p))
         steps_p = max(3, args.steps // 4)
         o = {"M_queries_per_s": round(nq_p * steps_p / el_p / 1e6, 1), "G_hits_per_s": round(cn["n_hits"] * steps_p / el_p / 1e9, 1),
              "verified": bool(ok), "queries": nq_p,
@@ -662,6 +662,10 @@ def worker(args):
     length_probes = None
     if world == 1 and args.config == 2 and not args.no_other_configs and rank == 0 and args.n == n_cfg:
         length_probes = {f"m={m_}": length_probe(idx, text, args.sigma, m_) for m_ in (8, 9, 13, 25)}
+        # deeper than the prefix levels: lists merged per query (m = k - 4: 16 runs / 24 K positions, one chunk of k_prefix_merge_block;
+        # m = k - 5: 64 runs / 98 K positions, value bands) — few queries, each a long list; fewer of them re-read
+        if ks == [10] and args.n >= 50_000_000:
+            length_probes.update({f"m={m_}": length_probe(idx, text, args.sigma, m_, nq_p, nv_p=nv_) for m_, nq_p, nv_ in ((6, 20_000, 200), (5, 4_000, 40))})
         if any(not v["verified"] for v in length_probes.values()):
             verified = False
             log("VERIFICATION FAILED in length_probes")

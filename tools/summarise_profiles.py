@@ -37,7 +37,7 @@ def counters(path, counter):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
-    ap.add_argument("--round", default="r03")
+    ap.add_argument("--round", default="r04")
     ap.add_argument("--config", type=int, default=2)
     a = ap.parse_args()
     sfx = "" if a.config == 2 else f"_cfg{a.config}"

@@ -21,7 +21,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("tag")
     ap.add_argument("--config", default="3")
-    ap.add_argument("--round", default="r03")
+    ap.add_argument("--round", default="r04")
     a = ap.parse_args()
     src = os.path.join(ROOT, "gpurun_out", f"sq_{a.tag}_cfg{a.config}")
     per = defaultdict(lambda: defaultdict(list))
