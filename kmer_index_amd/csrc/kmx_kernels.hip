@@ -3542,6 +3542,41 @@ __device__ __forceinline__ uint32_t merge_path_cut(PA A, uint32_t na, PB B, uint
 // Buffers alternate between `out` (slice of query q at hit_off[q]) and `tmp` (at tile_off[i] * KMX_PM_TILE); a query with
 // P passes starts in the buffer that makes its LAST pass land in `out` (k_prefix_sort_block writes there), so there is
 // no copy back, and a query is not touched by passes beyond its own.
+// merge_path_cut by a WAVE: 64 probes of the bracket per round trip instead of one (a tile of k_prefix_merge_pass started behind
+// some thirty dependent round trips to global memory — its place in the tile table, its slice's descriptor, two merge-path
+// searches of up to twenty steps by one thread each — and the passes ran at 2.6 TB/s algorithmic for it).  Returns the same cut in
+// every lane.
+template <typename PA, typename PB>
+__device__ __forceinline__ uint32_t merge_path_cut_wave(PA A, uint32_t na, PB B, uint32_t nb, uint32_t dg, uint32_t lane)
+{
+    uint32_t lo = dg > nb ? dg - nb : 0u, hi = min(dg, na);      // the cut is in [lo, hi]; A[a] < B[dg - 1 - a] holds below it, not from it on
+    while (lo < hi) {
+        const uint32_t n = hi - lo, step = (n + KMX_WAVE - 1) / KMX_WAVE;
+        const uint32_t a = lo + lane * step;                      // lane i asks about a_i = lo + i step (those below hi)
+        const bool below = a < hi && A[a] < B[dg - 1 - a];
+        const uint32_t c = uint32_t(__popcll(__ballot(below)));   // the a_i the cut lies above: a prefix of the lanes
+        const uint32_t nlo = c ? lo + (c - 1) * step + 1 : lo;    // above a_(c-1) ...
+        hi = min(hi, lo + c * step);                              // ... and not above a_c
+        lo = nlo;
+    }
+    return lo;
+}
+// first index i in [0, n) with a[i] > x, by a wave (n >= 1, a ascending, a[0] <= x)
+__device__ __forceinline__ uint64_t upper_bound_wave(const uint64_t* __restrict__ a, uint64_t n, uint64_t x, uint32_t lane)
+{
+    uint64_t lo = 0, hi = n;                                      // the answer is in [lo, hi]
+    while (lo < hi) {
+        const uint64_t m = hi - lo, step = (m + KMX_WAVE - 1) / KMX_WAVE;
+        const uint64_t at = lo + lane * step;
+        const bool le = at < hi && a[at] <= x;
+        const uint64_t c = uint64_t(__popcll(__ballot(le)));
+        const uint64_t nlo = c ? lo + (c - 1) * step + 1 : lo;
+        hi = min(hi, lo + c * step);
+        lo = nlo;
+    }
+    return lo;
+}
+
 __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_pass(QueryDesc d, uint64_t n_prefix,
                                                                  const uint64_t* __restrict__ tile_off,
                                                                  const uint64_t* __restrict__ hit_off,
@@ -3553,7 +3588,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_pass(QueryDesc d, ui
     __shared__ uint32_t cut[2];
     const uint64_t b = blockIdx.x;
     if (b >= tile_off[n_prefix]) return;
-    const uint64_t i = upper_bound_dev<uint64_t>(tile_off, n_prefix + 1, b) - 1;
+    const uint64_t i = upper_bound_wave(tile_off, n_prefix + 1, b, lane_id()) - 1;        // (every wave of the block for itself: no barrier)
     const uint32_t q = d.prefix_list[i];
     const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
     const uint32_t P = prefix_merge_passes(len);
@@ -3577,8 +3612,13 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_merge_pass(QueryDesc d, ui
     }
     const uint32_t* __restrict__ A = src + a_lo;
     const uint32_t* __restrict__ B = src + a_hi;
-    if (tid == 0) cut[0] = merge_path_cut(A, na, B, nb, d0);
-    if (tid == KMX_WAVE) cut[1] = merge_path_cut(A, na, B, nb, d1);
+    if (tid < KMX_WAVE) {                                                        // wave 0: where the tile starts on the merge path ...
+        const uint32_t c0 = merge_path_cut_wave(A, na, B, nb, d0, tid);
+        if (tid == 0) cut[0] = c0;
+    } else if (tid < 2 * KMX_WAVE) {                                             // ... wave 1: where it ends
+        const uint32_t c1 = merge_path_cut_wave(A, na, B, nb, d1, tid - KMX_WAVE);
+        if (tid == KMX_WAVE) cut[1] = c1;
+    }
     __syncthreads();
     const uint32_t a0 = cut[0], a1 = cut[1], b0 = d0 - a0;
     const uint32_t nA = a1 - a0, nB = n_out - nA;
