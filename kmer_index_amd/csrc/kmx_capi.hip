@@ -111,11 +111,11 @@ struct HostBuf {
 
 enum KernelId {
     K_LOOKUP = 0, K_SCAN, K_PARTITION, K_FILL, K_VALIDATE, K_COMPACT, K_PREFIX_LEN, K_MERGE_PASS,
-    K_PREFIX_SORT_SMALL, K_PREFIX_MERGE_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_PREFIX_BANDS, K_COUNT
+    K_PREFIX_SORT_SMALL, K_PREFIX_MERGE_SMALL, K_PREFIX_SORT_BLOCK, K_SMALL, K_PREFIX_BANDS, K_PREFIX_SPLIT, K_COUNT
 };
 const char* const kKernelNames[K_COUNT] = {
     "k_lookup", "k_scan", "k_partition", "k_fill", "k_validate", "k_compact",
-    "k_prefix_len", "k_prefix_merge_pass", "k_prefix_sort_small", "k_prefix_merge_small", "k_prefix_sort_block", "k_small", "k_prefix_bands"};
+    "k_prefix_len", "k_prefix_merge_pass", "k_prefix_sort_small", "k_prefix_merge_small", "k_prefix_sort_block", "k_small", "k_prefix_bands", "k_prefix_split"};
 
 struct Stats {
     bool enabled = false;
@@ -232,7 +232,7 @@ struct kmx_result {
     uint64_t n_mask_words = 0;
     // device
     DevBuf src, cnt, c0, aux, key, p1, kind, status, stitch_list, prefix_list, short_list, hit_off, bsum, ctr, tile_q, out,
-        mask_words, stitch_hits, plen, poff, ptmp, pitems, pbands, pcuts, pbanded, in_qranks, in_qoff;
+        mask_words, stitch_hits, plen, poff, ptmp, pitems, pbands, pcuts, pbanded, psplits, ptiles, pscnt, pscratch, in_qranks, in_qoff;
     unsigned long long* h_ctr = nullptr;   // pinned
     // host mirrors
     HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src, h_small;
@@ -274,7 +274,7 @@ struct kmx_result {
     {
         size_t b = 0;
         for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &short_list, &hit_off, &bsum, &ctr,
-                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &in_qranks, &in_qoff, &small_xchg})
+                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &psplits, &ptiles, &pscnt, &pscratch, &in_qranks, &in_qoff, &small_xchg})
             b += d->cap;
         return b;
     }
@@ -282,7 +282,7 @@ struct kmx_result {
     void release()
     {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &short_list, &hit_off, &bsum, &ctr,
-                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &in_qranks, &in_qoff, &small_xchg})
+                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &psplits, &ptiles, &pscnt, &pscratch, &in_qranks, &in_qoff, &small_xchg})
             b->release();
         for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox, &small_in})
             b->release();
@@ -1664,21 +1664,50 @@ static kmx_status search_finish(kmx_result* r)
         // the slices beyond the 256-thread shape: cut into bands where that works (k_prefix_bands: cut tables + one record per band), the
         // others as chunks (k_prefix_items: one record per chunk — one per slice + one per full chunk at most)
         const uint64_t n_mid = r->h_ctr[KMX_CTR_PREFIX_MID], n_long = np > n_mid ? np - n_mid : 0;
-        const uint64_t cap_items = n_long ? n_long + prefix_elems / KMX_PSORT_BLOCK_CAP : 0;
+        static const bool no_bands = getenv("KMX_NO_BANDS") != nullptr;                 // (experiments: everything as chunks)
+        static const bool no_split = getenv("KMX_NO_SPLIT") != nullptr || no_bands;     // (... no slice spread by value)
+        // room for the slices spread by value (k_prefix_split_*): only slices beyond one chunk go there, prefix_elems holds their positions
+        const bool split_ok = large && !no_split;
+        const uint64_t n_large_max = prefix_elems / KMX_PSORT_BLOCK_CAP + 1;
+        kmx::PrefixSplitRoom sr{};
+        if (split_ok) {
+            sr.cap_splits = n_large_max;
+            sr.cap_tiles = prefix_elems / kmx::prefix_split_tile() + n_large_max;
+            sr.cap_counters = 3 * (prefix_elems / kmx::prefix_split_target() + n_large_max);
+            sr.cap_scratch = prefix_elems + 4 * n_large_max;
+        }
+        const uint64_t cap_items = n_long ? n_long + prefix_elems / KMX_PSORT_BLOCK_CAP + (split_ok ? prefix_elems / kmx::prefix_split_target() + n_large_max : 0) : 0;
         const uint64_t cap_bands = n_long ? n_long * (KMX_PSORT_BLOCK_CAP / kmx::prefix_band_target() + 1) + prefix_elems / kmx::prefix_band_target() : 0;
         const uint64_t cap_cuts = std::min<uint64_t>((cap_bands + n_long) * kmx::prefix_band_runs(), uint64_t(1) << 26);
-        static const bool no_bands = getenv("KMX_NO_BANDS") != nullptr;                 // (experiments: everything as chunks)
         if (n_long) {
             HIP_TRY(r->pitems.ensure(cap_items * kmx::prefix_item_bytes()));
             HIP_TRY(r->pbands.ensure(cap_bands * kmx::prefix_item_bytes()));
             HIP_TRY(r->pcuts.ensure(cap_cuts * 4));
             HIP_TRY(r->pbanded.ensure(np * 4));
+            if (split_ok) {
+                if (r->psplits.ensure(sr.cap_splits * kmx::prefix_split_bytes(0)) == hipSuccess && r->ptiles.ensure(sr.cap_tiles * kmx::prefix_split_bytes(1)) == hipSuccess &&
+                    r->pscnt.ensure(sr.cap_counters * 4) == hipSuccess && r->pscratch.ensure(sr.cap_scratch * 4) == hipSuccess) {
+                    sr.splits = r->psplits.p; sr.tiles = r->ptiles.p; sr.counters = r->pscnt.as<uint32_t>(); sr.scratch = r->pscratch.as<uint32_t>();
+                    HIP_TRY(hipMemsetAsync(sr.splits, 0, sr.cap_splits * kmx::prefix_split_bytes(0), s));
+                    HIP_TRY(hipMemsetAsync(sr.tiles, 0xFF, sr.cap_tiles * kmx::prefix_split_bytes(1), s));
+                    HIP_TRY(hipMemsetAsync(sr.counters, 0, sr.cap_counters * 4, s));
+                } else {
+                    (void)hipGetLastError();                         // no room: those slices go through chunks + merge passes
+                    sr = kmx::PrefixSplitRoom{};
+                }
+            }
             if (no_bands) HIP_TRY(hipMemsetAsync(r->pbanded.p, 0, np * 4, s));
-            else
+            else {
                 timed(ix, K_PREFIX_BANDS, s, [&] {
                     kmx::launch_prefix_bands(s, dix, qo, d_big, np, hit_off, ix->d_arena, r->pbanded.as<uint32_t>(), r->pbands.p, cap_bands,
-                                             r->pcuts.as<uint32_t>(), cap_cuts, ctr + KMX_CTR_PSB_BANDS);
+                                             r->pcuts.as<uint32_t>(), cap_cuts, ctr + KMX_CTR_PSB_BANDS, sr);
                 });
+                if (sr.splits)
+                    timed(ix, K_PREFIX_SPLIT, s, [&] {
+                        kmx::launch_prefix_split(s, sr, ctr + KMX_CTR_PSB_BANDS, ix->d_arena, r->pbanded.as<uint32_t>(), ix->h_header.n, r->pitems.p, cap_items,
+                                                 ctr + KMX_CTR_PSB_OTHER);
+                    });
+            }
         }
         if (large) {
             HIP_TRY(r->plen.ensure(np * 4));
@@ -1693,7 +1722,7 @@ static kmx_status search_finish(kmx_result* r)
         timed(ix, K_PREFIX_SORT_BLOCK, s, [&] {
             kmx::launch_prefix_sort_block(s, dix, qo, d_big, np, n_mid, hit_off, ix->d_arena, out, large ? r->poff.as<uint64_t>() : nullptr,
                                           large ? r->ptmp.as<uint32_t>() : nullptr, r->pitems.p, cap_items, ctr + KMX_CTR_PSB_MERGE,
-                                          r->pbanded.as<uint32_t>(), r->pbands.p, cap_bands, r->pcuts.as<uint32_t>(), ctr + KMX_CTR_PSB_BANDS, ix->d_dbg);
+                                          r->pbanded.as<uint32_t>(), r->pbands.p, cap_bands, r->pcuts.as<uint32_t>(), ctr + KMX_CTR_PSB_BANDS, sr.scratch, ix->d_dbg);
         });
         if (large) {
             uint32_t passes = 0;

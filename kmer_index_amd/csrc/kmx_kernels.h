@@ -109,16 +109,30 @@ void launch_prefix_merge_small(hipStream_t s, const KmxIndexDev* ix, const uint6
 // them, 0 for every other listed slice.  bands: cap_bands records of prefix_item_bytes() each, cap_bands >= 6 per listed slice beyond
 // KMX_PSORT_MID_CAP + (positions of the slices beyond KMX_PSORT_BLOCK_CAP) / prefix_band_target(); cuts: cap_cuts words (a slice that
 // finds no room stays with the chunks); used: two zeroed device counters (KMX_CTR_PSB_BANDS, KMX_CTR_PSB_CUTS)
+// ... and the slices beyond one chunk with too many runs for bands are SPREAD BY VALUE (banded[i] = 2): room for their records
+// (prefix_split_bytes(0) each, cleared), their tiles (prefix_split_bytes(1) each, filled with 0xFF), their counters (words, cleared) and
+// their positions (words); splits == nullptr: none.  used: SIX zeroed device counters (KMX_CTR_PSB_BANDS ...)
+struct PrefixSplitRoom {
+    void* splits; uint64_t cap_splits;       // >= slices beyond KMX_PSORT_BLOCK_CAP
+    void* tiles; uint64_t cap_tiles;         // >= their positions / prefix_split_tile() + their number
+    uint32_t* counters; uint64_t cap_counters;   // >= 3 * (their positions / prefix_split_target() + their number)
+    uint32_t* scratch; uint64_t cap_scratch;     // >= their positions + 4 * their number
+};
 void launch_prefix_bands(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off,
                          const uint32_t* arena, uint32_t* banded, void* bands, uint64_t cap_bands, uint32_t* cuts, uint64_t cap_cuts,
-                         unsigned long long* used);
+                         unsigned long long* used, const PrefixSplitRoom& sr);
+void launch_prefix_split(hipStream_t s, const PrefixSplitRoom& sr, const unsigned long long* used, const uint32_t* arena, uint32_t* banded, uint64_t n_text,
+                         void* items, uint64_t cap_items, unsigned long long* n_other);
+uint64_t prefix_split_bytes(int what);
+uint64_t prefix_split_target();
+uint64_t prefix_split_tile();
 // items: room for cap_items records of prefix_item_bytes() each, cap_items >= (listed slices beyond KMX_PSORT_MID_CAP) + (positions of the
 // slices beyond KMX_PSORT_BLOCK_CAP) / KMX_PSORT_BLOCK_CAP; n_items: two zeroed device counters (KMX_CTR_PSB_MERGE, KMX_CTR_PSB_OTHER);
 // banded / bands / cuts / n_bands: what launch_prefix_bands left; dbg: the index's debug words
 void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp,
                               void* items, uint64_t cap_items, unsigned long long* n_items, const uint32_t* banded, const void* bands, uint64_t cap_bands,
-                              const uint32_t* cuts, const unsigned long long* n_bands, unsigned long long* dbg);
+                              const uint32_t* cuts, const unsigned long long* n_bands, const uint32_t* split, unsigned long long* dbg);
 uint64_t prefix_item_bytes();
 uint64_t prefix_band_target();
 uint64_t prefix_band_runs();

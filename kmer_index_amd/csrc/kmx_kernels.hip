@@ -3856,13 +3856,15 @@ typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
 #define KMX_PBK_GIVE_UP 48
 template <int THREADS, int CAP>
 __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wsum,
-                                                    const uint32_t* __restrict__ seg, uint32_t c_len, uint64_t n_text, uint32_t tid)
+                                                    const uint32_t* __restrict__ seg, uint32_t c_len, uint32_t v_lo, uint64_t v_width, uint32_t tid)
 {
+    // (the positions lie in [v_lo, v_lo + v_width): the whole text for a chunk of a slice, a band's stretch of it for a band
+    //  of k_prefix_split_*)
     constexpr int E = CAP / THREADS;                              // positions per thread
     constexpr int BPT = KMX_PBK_NB / THREADS;                     // buckets per thread in the scan and the bucket sorts
     static_assert(CAP % THREADS == 0 && KMX_PBK_NB % THREADS == 0 && BPT % 2 == 0 && BPT <= 8, "two counters per word, a thread's counters in one 16-byte read");
     static_assert(CAP <= 65535 && KMX_PBK_NB <= (1 << 13), "16-bit counters; bucket and slot share a word");
-    const uint32_t mul = uint32_t((uint64_t(KMX_PBK_NB) << 32) / n_text);     // floor: (p * mul) >> 32 < NB for every p < n
+    const uint32_t mul = uint32_t(min((uint64_t(KMX_PBK_NB) << 32) / max(v_width, uint64_t(1)), uint64_t(0xFFFFFFFFu)));     // floor: ((p - lo) * mul) >> 32 < NB for every p - lo < width
     for (uint32_t i = tid; i < KMX_PBK_NB / 2; i += THREADS) cnt[i] = 0;
     if (tid == 0) wsum[THREADS / 64] = 0;                         // the longest bucket
     __syncthreads();
@@ -3878,7 +3880,7 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
             const uint32_t i = uint32_t(2 * j2 + h) * THREADS + tid;
             uint32_t old = 0, sh = 0;
             if (i < c_len) {
-                const uint32_t b = __umulhi(seg[i], mul);
+                const uint32_t b = min(__umulhi(seg[i] - v_lo, mul), uint32_t(KMX_PBK_NB - 1));
                 sh = 16u * (b & 1u);
                 old = atomicAdd(&cnt[b >> 1], 1u << sh);
             }
@@ -3929,7 +3931,7 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
         const uint32_t i = uint32_t(j) * THREADS + tid;
         if (i < c_len) {
             const uint32_t p = seg[i];
-            const uint32_t b = __umulhi(p, mul), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+            const uint32_t b = min(__umulhi(p - v_lo, mul), uint32_t(KMX_PBK_NB - 1)), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
             const uint32_t place = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
             out[place + slot] = p;
         }
@@ -3973,14 +3975,14 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
 template <int THREADS, int CAP, int RUNS, bool MID>
 __device__ __forceinline__ void psb_chunk(uint32_t* __restrict__ sbuf, uint32_t* __restrict__ bnd, uint32_t* __restrict__ ptab,
                                           const uint32_t* __restrict__ seg, uint32_t* __restrict__ dst, const KMX_GLOBAL uint32_t* runs,
-                                          uint32_t base, uint32_t c_len, uint32_t Rc, uint64_t n_text, uint32_t tid)
+                                          uint32_t base, uint32_t c_len, uint32_t Rc, uint32_t v_lo, uint64_t v_width, uint32_t tid)
 {
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
     const bool merge = Rc <= RUNS;
     if constexpr (!MID) if (!merge) {
         // more runs than the merge takes: the distribution sort (it gives up on a repeat of the text: the network below)
         __shared__ uint32_t wsum[THREADS / 64 + 2];
-        if (distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, seg, c_len, n_text, tid)) {
+        if (distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, seg, c_len, v_lo, v_width, tid)) {
             for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
             __syncthreads();
             return;
@@ -4067,7 +4069,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_block(const KmxIndex
         const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
         if (len > CAP) continue;                                                          // the 1024-thread kernels' (block-uniform)
         const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);   // R + 1 run boundaries
-        psb_chunk<THREADS, CAP, RUNS, true>(sbuf, bnd, ptab, arena + (d.src[q] & ~SRC_FLAGS), out + hit_off[q], offs, offs[0], len, R, ix->n, tid);
+        psb_chunk<THREADS, CAP, RUNS, true>(sbuf, bnd, ptab, arena + (d.src[q] & ~SRC_FLAGS), out + hit_off[q], offs, offs[0], len, R, 0u, ix->n, tid);
     }
 }
 
@@ -4103,7 +4105,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_items(const KmxIndexDev* _
     const uint32_t n_chunks = (len + CAP - 1) / CAP;
     // where the chunks go: `out`, or the scratch buffer when the slice needs an odd number of merge passes
     const uint64_t dst0 = (prefix_merge_passes(len) & 1u) ? (tile_off[i] * KMX_PM_TILE) | KMX_PSB_TMP : hit_off[q];
-    const uint64_t src0 = d.src[q] & ~SRC_FLAGS;
+    const uint64_t src0 = d.src[q] & ~SRC_FLAGS, n_text = ix->n;
     const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);       // R + 1 run boundaries
     const uint32_t offs0 = offs[0];
     for (uint32_t c0 = 0; c0 < n_chunks; c0 += KMX_WAVE) {
@@ -4131,7 +4133,9 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_items(const KmxIndexDev* _
                 PsbItem it;
                 it.seg = src0 + c_lo;
                 it.dst = dst0 + c_lo;
-                it.runs = (const uint32_t*)(offs + r0);
+                // (a chunk the merge does not take has no use for its run boundaries: the record says where its positions lie
+                //  instead — anywhere in the text — as k_prefix_split_scan's records do for their bands)
+                it.runs = merge ? (const uint32_t*)(offs + r0) : reinterpret_cast<const uint32_t*>(uintptr_t(0) | (uintptr_t(uint32_t(min(n_text, uint64_t(0xFFFFFFFFu)))) << 32));
                 it.len_runs = c_len | (min(Rc, 0xFFFFu) << 16);
                 it.base = offs0 + c_lo;
                 items[at] = it;
@@ -4294,13 +4298,14 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem
     }
 }
 
-// The items the merge does not take (more than RUNS runs in a chunk: distribution sort / bitonic network), from the back of the
-// item array.
+// The items the merge does not take, from the back of the item array: chunks of more than RUNS runs (k_prefix_items), and the
+// bands of the slices k_prefix_split_* spread by value (positions in no order at all, in the scratch buffer `split`) — distribution
+// sort over the stretch of the text the record names, bitonic network where positions crowd.
 template <int THREADS, int CAP, int RUNS>
-__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const KmxIndexDev* __restrict__ ix, const PsbItem* __restrict__ items, uint64_t cap_items,
+__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const PsbItem* __restrict__ items, uint64_t cap_items,
                                                                 const unsigned long long* __restrict__ n_items_p,
-                                                                const uint32_t* __restrict__ arena, uint32_t* __restrict__ out,
-                                                                uint32_t* __restrict__ tmp)
+                                                                const uint32_t* __restrict__ arena, const uint32_t* __restrict__ split,
+                                                                uint32_t* __restrict__ out, uint32_t* __restrict__ tmp)
 {
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
     extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS + the distribution sort's counters
@@ -4310,9 +4315,195 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const KmxIndex
     for (uint64_t j = blockIdx.x; j < n_items; j += gridDim.x) {
         const PsbItem it = items[cap_items - 1 - j];
         uint32_t* dst = (it.dst & KMX_PSB_TMP) ? tmp + (it.dst & ~KMX_PSB_TMP) : out + it.dst;
+        const uint32_t* seg = (it.seg & KMX_PSB_TMP) ? split + (it.seg & ~KMX_PSB_TMP) : arena + it.seg;
         const uint32_t c_len = it.len_runs & 0xFFFFu;
+        const uint64_t range = reinterpret_cast<uintptr_t>(it.runs);            // v_lo | v_width << 32 (k_prefix_items, k_prefix_split_scan)
         // (the run count of such a chunk is only known to be beyond RUNS: the record holds min(runs, 0xFFFF))
-        psb_chunk<THREADS, CAP, RUNS, false>(sbuf, bnd, ptab, arena + it.seg, dst, as_global(it.runs), it.base, c_len, it.len_runs >> 16, ix->n, threadIdx.x);
+        psb_chunk<THREADS, CAP, RUNS, false>(sbuf, bnd, ptab, seg, dst, nullptr, it.base, c_len, 0xFFFFu, uint32_t(range), range >> 32, threadIdx.x);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// SPLITS.  A slice beyond one chunk whose runs are too many for bands (k_prefix_bands' cut table has a row per band of an entry per
+// run) — a prefix far below k, or any prefix on an element of a large k, where every run is a position or two — went through
+// chunks sorted in LDS and ceil(log2 chunks) merge passes, 8 bytes per position and pass (16 384 runs / 1.56 M positions: six
+// passes, 8.2 of 10.3 ms).  Here its positions are spread by VALUE first, like the digits of a radix sort: band b of S takes the
+// positions p with floor(p S / n) = b (about KMX_SPLIT of them), and every band is then ONE chunk for k_prefix_sort_items —
+// 20 bytes per position in all, no passes.
+//   k_prefix_bands        (the same wave that decides about bands) a record per slice, its counters, a list of its tiles
+//   k_prefix_split_count  a block per tile of KMX_SPLIT_TILE positions: LDS histogram of the bands, added to the slice's counters
+//   k_prefix_split_scan   a wave per slice: the bands' places (exclusive scan), one item per band — or, when a band would not fit a
+//                         chunk (occurrences that cluster), the slice handed back to the chunks (banded[i] = 0)
+//   k_prefix_split_scatter a block per tile again: positions binned by band in LDS, every bin appended to its band in `split`
+// ---------------------------------------------------------------------------
+#define KMX_SPLIT 24576            // positions per band aimed at (a band takes up to KMX_PSORT_BLOCK_CAP)
+#define KMX_SPLIT_MAX 1024         // bands per slice at most (LDS histograms)
+#define KMX_SPLIT_TILE 8192        // positions per block of the count / scatter kernels
+struct PsbSplit {
+    uint64_t src0;                 // the slice's first position in the arena
+    uint64_t dst0;                 // ... in `out`
+    uint64_t tmp0;                 // ... in the scratch buffer
+    uint32_t len, S;               // positions, bands (0: handed back to the chunks)
+    uint32_t cnt_at;               // the slice's counters: S counts, S places, S fill cursors
+    uint32_t list_i;               // its place in the work list (banded[list_i])
+    uint32_t mul;                  // band of p = (p * mul) >> 32
+    uint32_t pad;
+};
+static_assert(sizeof(PsbSplit) == 48, "three 16-byte loads");
+struct PsbTile { uint32_t split, tile; };           // (split == 0xFFFFFFFF: no tile)
+struct SplitRoom {                                  // what k_prefix_bands may hand out to the slices it sends this way (splits == nullptr: none)
+    PsbSplit* splits; uint64_t cap_splits;
+    PsbTile* tiles; uint64_t cap_tiles;
+    uint64_t cap_counters, cap_scratch;             // words
+};
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_prefix_split_count(const PsbSplit* __restrict__ splits, const PsbTile* __restrict__ tiles, uint64_t cap_tiles,
+                                                                const unsigned long long* __restrict__ n_tiles_p, const uint32_t* __restrict__ arena,
+                                                                uint32_t* __restrict__ counters)
+{
+    __shared__ uint32_t hist[KMX_SPLIT_MAX];
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_tiles = min((uint64_t)*n_tiles_p, cap_tiles);
+    for (uint64_t j = blockIdx.x; j < n_tiles; j += gridDim.x) {
+        const PsbTile t = tiles[j];
+        if (t.split == 0xFFFFFFFFu) continue;                      // (block-uniform)
+        const PsbSplit sp = splits[t.split];
+        const uint32_t t0 = t.tile * KMX_SPLIT_TILE, n = min(uint32_t(KMX_SPLIT_TILE), sp.len - t0);
+        for (uint32_t b = tid; b < sp.S; b += THREADS) hist[b] = 0;
+        __syncthreads();
+        const uint32_t* __restrict__ seg = arena + sp.src0 + t0;
+        for (uint32_t e = tid * 4; e < n; e += THREADS * 4) {
+            const u32x4 v = *reinterpret_cast<const u32x4_a4*>(seg + e);          // (the arena is padded: the quad at the tile's end is whole)
+            atomicAdd(&hist[__umulhi(v.x, sp.mul)], 1u);
+            if (e + 1 < n) atomicAdd(&hist[__umulhi(v.y, sp.mul)], 1u);
+            if (e + 2 < n) atomicAdd(&hist[__umulhi(v.z, sp.mul)], 1u);
+            if (e + 3 < n) atomicAdd(&hist[__umulhi(v.w, sp.mul)], 1u);
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < sp.S; b += THREADS)
+            if (hist[b]) atomicAdd(&counters[sp.cnt_at + b], hist[b]);
+        __syncthreads();
+    }
+}
+
+template <int CAP>
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_split_scan(PsbSplit* __restrict__ splits, uint64_t cap_splits, const unsigned long long* __restrict__ n_splits_p,
+                                                                 uint32_t* __restrict__ counters, uint32_t* __restrict__ banded, uint64_t n_text,
+                                                                 PsbItem* __restrict__ items, uint64_t cap_items, unsigned long long* __restrict__ n_other)
+{
+    const uint32_t lane = lane_id();
+    const uint64_t w = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
+    if (w >= min((uint64_t)*n_splits_p, cap_splits)) return;
+    PsbSplit sp = splits[w];
+    if (sp.S == 0) return;                                         // (a record that was never written)
+    uint32_t* __restrict__ cnt = counters + sp.cnt_at;
+    uint32_t* __restrict__ place = cnt + sp.S;
+    // the bands' places, and whether every band fits a chunk
+    uint32_t carry = 0, biggest = 0;
+    for (uint32_t b0 = 0; b0 < sp.S; b0 += KMX_WAVE) {
+        const uint32_t b = b0 + lane, c = b < sp.S ? cnt[b] : 0u;
+        uint32_t inc = c;
+#pragma unroll
+        for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
+            const uint32_t t = __shfl_up(inc, o);
+            if (lane >= o) inc += t;
+        }
+        if (b < sp.S) place[b] = carry + inc - c;
+        carry += __shfl(inc, KMX_WAVE - 1);
+        biggest = max(biggest, c);
+    }
+#pragma unroll
+    for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) biggest = max(biggest, uint32_t(__shfl_xor(int(biggest), int(o))));
+    unsigned long long at = 0;
+    const bool fits = biggest <= CAP && carry == sp.len;
+    if (fits && lane == 0) at = atomicAdd(n_other, (unsigned long long)sp.S);
+    at = __shfl(at, 0);
+    if (!fits || at + sp.S > cap_items) {                          // occurrences cluster: chunks + merge passes for this slice
+        if (lane == 0) { banded[sp.list_i] = 0; splits[w].S = 0; }
+        return;
+    }
+    for (uint32_t b = lane; b < sp.S; b += KMX_WAVE) {
+        // band b holds the positions p with (p * mul) >> 32 == b: from ceil(b 2^32 / mul) up to where band b + 1 starts
+        const uint64_t lo = ((uint64_t(b) << 32) + sp.mul - 1) / sp.mul, hi = min(((uint64_t(b + 1) << 32) + sp.mul - 1) / sp.mul, n_text);
+        PsbItem it;
+        it.seg = (sp.tmp0 + place[b]) | KMX_PSB_TMP;
+        it.dst = sp.dst0 + place[b];
+        it.runs = reinterpret_cast<const uint32_t*>(uintptr_t(lo) | (uintptr_t(uint32_t(hi > lo ? hi - lo : 1)) << 32));
+        it.len_runs = cnt[b] | (0xFFFFu << 16);
+        it.base = 0;
+        items[cap_items - 1 - (at + b)] = it;
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit* __restrict__ splits, const PsbTile* __restrict__ tiles, uint64_t cap_tiles,
+                                                                  const unsigned long long* __restrict__ n_tiles_p, const uint32_t* __restrict__ arena,
+                                                                  uint32_t* __restrict__ counters, uint32_t* __restrict__ split)
+{
+    constexpr uint32_t PT = KMX_SPLIT_TILE / THREADS;              // positions per thread
+    constexpr uint32_t BPT = KMX_SPLIT_MAX / THREADS;              // bands per thread in the scan
+    __shared__ uint32_t hist[KMX_SPLIT_MAX];                       // positions of the tile per band, then the band's first slot in buf
+    __shared__ uint32_t gat[KMX_SPLIT_MAX];                        // where the tile's share of a band goes in the scratch buffer, minus its first slot
+    __shared__ uint32_t buf[KMX_SPLIT_TILE];
+    __shared__ uint32_t wsum[THREADS / KMX_WAVE];
+    const uint32_t tid = threadIdx.x, lane = tid & (KMX_WAVE - 1), wv = tid / KMX_WAVE;
+    const uint64_t n_tiles = min((uint64_t)*n_tiles_p, cap_tiles);
+    for (uint64_t j = blockIdx.x; j < n_tiles; j += gridDim.x) {
+        const PsbTile t = tiles[j];
+        if (t.split == 0xFFFFFFFFu) continue;                      // (block-uniform)
+        const PsbSplit sp = splits[t.split];
+        if (sp.S == 0) continue;                                   // handed back to the chunks (block-uniform)
+        const uint32_t t0 = t.tile * KMX_SPLIT_TILE, n = min(uint32_t(KMX_SPLIT_TILE), sp.len - t0);
+        for (uint32_t b = tid; b < KMX_SPLIT_MAX; b += THREADS) hist[b] = 0;
+        __syncthreads();
+        const uint32_t* __restrict__ seg = arena + sp.src0 + t0;
+        uint32_t val[PT], slot[PT];                                // a position and its number inside its band's share of the tile
+#pragma unroll
+        for (uint32_t u = 0; u < PT; ++u) {
+            const uint32_t e = u * THREADS + tid;
+            if (e < n) {
+                val[u] = seg[e];
+                slot[u] = atomicAdd(&hist[__umulhi(val[u], sp.mul)], 1u);
+            }
+        }
+        __syncthreads();
+        {
+            // exclusive scan of the counts (thread t: bands BPT t ..), and the tile's claim on every band it holds positions of
+            uint32_t c[BPT], total = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < BPT; ++u) { c[u] = hist[tid * BPT + u]; total += c[u]; }
+            uint32_t inc = total;
+#pragma unroll
+            for (uint32_t o = 1; o < KMX_WAVE; o <<= 1) {
+                const uint32_t x = __shfl_up(inc, o);
+                if (lane >= o) inc += x;
+            }
+            if (lane == KMX_WAVE - 1) wsum[wv] = inc;
+            __syncthreads();
+            uint32_t first = inc - total;
+            for (uint32_t w2 = 0; w2 < wv; ++w2) first += wsum[w2];
+#pragma unroll
+            for (uint32_t u = 0; u < BPT; ++u) {
+                const uint32_t b = tid * BPT + u;
+                hist[b] = first;
+                if (c[u]) gat[b] = counters[sp.cnt_at + sp.S + b] + atomicAdd(&counters[sp.cnt_at + 2 * sp.S + b], c[u]) - first;
+                first += c[u];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t u = 0; u < PT; ++u) {
+            const uint32_t e = u * THREADS + tid;
+            if (e < n) buf[hist[__umulhi(val[u], sp.mul)] + slot[u]] = val[u];
+        }
+        __syncthreads();
+        uint32_t* __restrict__ to = split + sp.tmp0;
+        for (uint32_t e = tid; e < n; e += THREADS) {              // (slot e of buf: consecutive slots of one band go to consecutive places)
+            const uint32_t p = buf[e];
+            to[gat[__umulhi(p, sp.mul)] + e] = p;
+        }
+        __syncthreads();
     }
 }
 
@@ -4374,7 +4565,8 @@ __device__ __forceinline__ uint32_t band_cut(const KMX_GLOBAL uint32_t* A, uint3
 __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_bands(const KmxIndexDev* __restrict__ ix, const uint64_t* __restrict__ qoff, QueryDesc d,
                                                             uint64_t n_prefix, const uint64_t* __restrict__ hit_off, const uint32_t* __restrict__ arena,
                                                             uint32_t* __restrict__ banded, PsbBand* __restrict__ bands, uint64_t cap_bands,
-                                                            uint32_t* __restrict__ cuts, uint64_t cap_cuts, unsigned long long* __restrict__ used)
+                                                            uint32_t* __restrict__ cuts, uint64_t cap_cuts, unsigned long long* __restrict__ used,
+                                                            SplitRoom room)
 {
     __shared__ uint32_t sums[KMX_BLOCK / KMX_WAVE][KMX_BAND_MAX + 1];                     // sums[s] = positions of the slice below threshold s
     const uint32_t lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
@@ -4393,7 +4585,42 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_bands(const KmxIndexDev* _
     // (a slice of one chunk stays a chunk: measured, 24 K positions of 16 runs take a 1024-thread block 5.5 ms per 5e4 slices and their
     //  four bands 5.2 + 1.2 for the cuts — the rounds, not the memory phases, are what both wait for; what the bands save is the
     //  merge passes behind the chunks of a longer slice: 98 K positions of 64 runs 10.1 -> 7.0 ms per 1e4 slices)
-    if (len <= KMX_PSORT_BAND_MIN || R < 2 || R > KMX_BAND_RUNS || S > KMX_BAND_MAX) { leave(); return; }
+    if (len <= KMX_PSORT_BAND_MIN || R < 2 || R > KMX_BAND_RUNS || S > KMX_BAND_MAX) {
+        // too many runs for bands, and more than one chunk: spread by value (k_prefix_split_*) — this wave makes the slice's record, its
+        // counters' and its scratch space's places and the list of its tiles
+        const uint32_t S2 = (len + KMX_SPLIT - 1) / KMX_SPLIT, n_tiles = (len + KMX_SPLIT_TILE - 1) / KMX_SPLIT_TILE;
+        if (room.splits && len > KMX_PSORT_BLOCK_CAP && R > KMX_BAND_RUNS && S2 <= KMX_SPLIT_MAX) {
+            unsigned long long si = 0, ca = 0, ta = 0, ti = 0;
+            if (lane == 0) {
+                si = atomicAdd(&used[2], 1ull);
+                ca = atomicAdd(&used[3], 3ull * S2);
+                ta = atomicAdd(&used[4], (unsigned long long)((len + 3u) & ~3u));
+                ti = atomicAdd(&used[5], (unsigned long long)n_tiles);
+            }
+            si = __shfl(si, 0); ca = __shfl(ca, 0); ta = __shfl(ta, 0); ti = __shfl(ti, 0);
+            // (the caller's room is an upper bound: these cannot fail; a record that is not written reads as 'no slice' — the caller
+            //  clears both lists)
+            if (si < room.cap_splits && ca + 3ull * S2 <= room.cap_counters && ta + len <= room.cap_scratch && ti + n_tiles <= room.cap_tiles) {
+                if (lane == 0) {
+                    PsbSplit sp;
+                    sp.src0 = d.src[q] & ~SRC_FLAGS;
+                    sp.dst0 = hit_off[q];
+                    sp.tmp0 = ta;
+                    sp.len = len; sp.S = S2;
+                    sp.cnt_at = uint32_t(ca);
+                    sp.list_i = uint32_t(i);
+                    sp.mul = uint32_t((uint64_t(S2) << 32) / ix->n);                 // floor: (p * mul) >> 32 < S2 for every p < n
+                    sp.pad = 0;
+                    room.splits[si] = sp;
+                    banded[i] = 2;
+                }
+                for (uint32_t t = lane; t < n_tiles; t += KMX_WAVE) room.tiles[ti + t] = PsbTile{uint32_t(si), t};
+                return;
+            }
+        }
+        leave();
+        return;
+    }
     // the slice's cut table: rows 0 .. S of R entries (row 0: zeros, row S: the runs' lengths)
     unsigned long long at = 0;
     if (lane == 0) at = atomicAdd(&used[1], (unsigned long long)(S + 1) * R);
@@ -4451,6 +4678,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_band(const PsbBand*
     for (uint64_t j = blockIdx.x; j < n_bands; j += gridDim.x) {
         const PsbBand b = bands[j];
         const uint32_t len = __builtin_amdgcn_readfirstlane(b.len_runs & 0xFFFFu), R = __builtin_amdgcn_readfirstlane(b.len_runs >> 16);
+        if (len == 0) continue;                                    // (a stretch of the text without any occurrence: block-uniform)
         if (tid < KMX_WAVE) {
             uint32_t n_r = 0, at = 0;
             if (tid < R) {
@@ -4534,11 +4762,30 @@ uint64_t prefix_band_runs() { return KMX_BAND_RUNS; }
 // used: two zeroed device counters (KMX_CTR_PSB_BANDS, KMX_CTR_PSB_CUTS)
 void launch_prefix_bands(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, const uint64_t* hit_off,
                          const uint32_t* arena, uint32_t* banded, void* bands, uint64_t cap_bands, uint32_t* cuts, uint64_t cap_cuts,
-                         unsigned long long* used)
+                         unsigned long long* used, const PrefixSplitRoom& sr)
 {
+    SplitRoom room{static_cast<PsbSplit*>(sr.splits), sr.cap_splits, static_cast<PsbTile*>(sr.tiles), sr.cap_tiles, sr.cap_counters, sr.cap_scratch};
     hipLaunchKernelGGL(k_prefix_bands, dim3(blocks_for(n_prefix * KMX_WAVE, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, arena,
-                       banded, static_cast<PsbBand*>(bands), cap_bands, cuts, cap_cuts, used);
+                       banded, static_cast<PsbBand*>(bands), cap_bands, cuts, cap_cuts, used, room);
 }
+
+// the slices launch_prefix_bands sent to be spread by value: counted, placed (their bands become items at the back of `items`, or the
+// slice goes back to the chunks: banded[i] = 0) and spread into sr.scratch.  used: the counters launch_prefix_bands counted into
+void launch_prefix_split(hipStream_t s, const PrefixSplitRoom& sr, const unsigned long long* used, const uint32_t* arena, uint32_t* banded, uint64_t n_text,
+                         void* items, uint64_t cap_items, unsigned long long* n_other)
+{
+    const unsigned int tb = (unsigned int)std::min<uint64_t>(std::max<uint64_t>(sr.cap_tiles, 1), 256 * 12);
+    const PsbSplit* sp = static_cast<const PsbSplit*>(sr.splits);
+    const PsbTile* tl = static_cast<const PsbTile*>(sr.tiles);
+    hipLaunchKernelGGL((k_prefix_split_count<256>), dim3(tb), dim3(256), 0, s, sp, tl, sr.cap_tiles, used + 5, arena, sr.counters);
+    hipLaunchKernelGGL((k_prefix_split_scan<KMX_PSORT_BLOCK_CAP>), dim3(blocks_for(sr.cap_splits * KMX_WAVE, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s,
+                       static_cast<PsbSplit*>(sr.splits), sr.cap_splits, used + 2, sr.counters, banded, n_text, static_cast<PsbItem*>(items), cap_items, n_other);
+    // (512 threads per tile: sixteen positions a thread — 24 waves per CU behind 44 KB of LDS a block instead of 12)
+    hipLaunchKernelGGL((k_prefix_split_scatter<512>), dim3(tb), dim3(512), 0, s, sp, tl, sr.cap_tiles, used + 5, arena, sr.counters, sr.scratch);
+}
+uint64_t prefix_split_bytes(int what) { return what == 0 ? sizeof(PsbSplit) : sizeof(PsbTile); }
+uint64_t prefix_split_target() { return KMX_SPLIT; }
+uint64_t prefix_split_tile() { return KMX_SPLIT_TILE; }
 
 // n_mid of the n_prefix listed queries have slices of at most KMX_PSORT_MID_CAP positions; banded / bands / cuts / n_bands: what
 // launch_prefix_bands left; items: room for cap_items records (>= one per listed slice beyond KMX_PSORT_MID_CAP + one per
@@ -4546,7 +4793,7 @@ void launch_prefix_bands(hipStream_t s, const KmxIndexDev* ix, const uint64_t* q
 void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp,
                               void* items, uint64_t cap_items, unsigned long long* n_items, const uint32_t* banded, const void* bands, uint64_t cap_bands,
-                              const uint32_t* cuts, const unsigned long long* n_bands, unsigned long long* dbg)
+                              const uint32_t* cuts, const unsigned long long* n_bands, const uint32_t* split, unsigned long long* dbg)
 {
     if (n_mid) {
         auto fn = k_prefix_sort_block<256, KMX_PSORT_MID_CAP, 64>;
@@ -4575,7 +4822,7 @@ void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64
             auto fn = k_prefix_sort_items<1024, KMX_PSORT_BLOCK_CAP, 128>;
             const size_t lds = size_t(PsbBig::WORDS + KMX_PBK_NB / 2) * 4;        // (+ the counters of the distribution sort)
             allow_big_lds(reinterpret_cast<const void*>(fn), lds, 2);
-            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(1024), lds, s, ix, it, cap_items, n_items + 1, arena, out, tmp);
+            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(1024), lds, s, it, cap_items, n_items + 1, arena, split, out, tmp);
         }
     }
 }

@@ -217,7 +217,8 @@ enum {
     KMX_CTR_PSB_OTHER = 19,    // ... and for k_prefix_sort_items (more runs than the merge takes)
     KMX_CTR_PSB_BANDS = 20,    // bands of the PREFIX slices k_prefix_bands cut (k_prefix_merge_band's work; KMX_CTR_PSB_CUTS follows it)
     KMX_CTR_PSB_CUTS = 21,     // words of cut tables handed out
-    KMX_CTR_COUNT = 24
+    KMX_CTR_PSB_SPLITS = 22,   // slices spread by value (k_prefix_split_*), then: words of their counters (23), of their scratch space (24), their tiles (25)
+    KMX_CTR_COUNT = 28
 };
 #define KMX_LONG_PARTS 256      // parts beyond which a query's probes are spread over the lanes of a wave instead of walked by one lane
                                 // (measured: 100 parts — 1000 letters on k = 10 — are faster walked, 0.76 against 2.5 ms per 1e5 reads: a

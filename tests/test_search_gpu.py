@@ -681,6 +681,7 @@ def test_prefix_sort_all_size_classes(engine, orc):
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
     k = idx.stats()
     assert k["k_prefix_sort_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_prefix_merge_pass"]["launches"]
+    assert k["k_prefix_split"]["launches"]                    # (m = 2: 37.5 K positions in 65536 runs — spread by value, two bands)
     # the same classes with LONG runs (146 positions per 6-mer): 4 runs / 586 positions (wave-level merge), 16 runs / 2.3 K and
     # 64 runs / 9.4 K (the two shapes of the block-level merge), 256 and 1024 runs (chunks + merge passes)
     idx6 = engine.Index(text, 4, [6], prefix_levels=-1)
@@ -695,6 +696,7 @@ def test_prefix_sort_all_size_classes(engine, orc):
     assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos)
     k = idx6.stats()
     assert k["k_prefix_merge_small"]["launches"] and k["k_prefix_sort_block"]["launches"] and k["k_prefix_merge_pass"]["launches"]
+    assert k["k_prefix_split"]["launches"]                    # (m = 1: 150 K positions in 1024 runs — seven bands; m = 2: 256 runs, two)
 
 
 @pytest.mark.parametrize("sigma,ks,levels", [(4, [10], 0), (4, [10], 1), (4, [10], 3), (4, [6, 9, 12], 0), (5, [8], 0), (20, [4], 0),
@@ -859,7 +861,11 @@ def test_prefix_slices_cut_into_bands(engine, orc):
     n = 3_000_000
     even = rng.integers(0, 4, n).astype(np.uint8)
     skew = np.concatenate([rng.integers(0, 2, n // 4), rng.integers(2, 4, n - n // 4)]).astype(np.uint8)
-    for text, sigma, ks in ((even, 4, [6]), (skew, 4, [6]), (even % 2, 2, [12])):
+    # the first fifth of the text without the letter A: the bands of 'AAA' there are empty, the others still fit
+    gap = rng.integers(0, 4, 2_720_000).astype(np.uint8)
+    gap[:544_000] = rng.integers(1, 4, 544_000)
+    for text, sigma, ks in ((even, 4, [6]), (skew, 4, [6]), (even % 2, 2, [12]), (gap, 4, [6])):
+        n = text.size
         idx = engine.Index(text, sigma, ks, prefix_levels=-1)
         oidx = orc.Index(text, sigma, ks)
         k = ks[0]
@@ -869,6 +875,7 @@ def test_prefix_slices_cut_into_bands(engine, orc):
         qs = [text[s0:s0 + m].copy() for m in lens for s0 in range(1000, 1000 + 53 * 24, 53)]
         qs += [rng.integers(0, sigma, m).astype(np.uint8) for m in lens for _ in range(8)]
         qs += [text[n - m:].copy() for m in lens]                                               # with last-kmer positions
+        qs += [np.zeros(m, np.uint8) for m in lens]                                              # A...A
         qranks, qoff = pack(qs)
         idx.stats_enable(True)
         r = idx.search(qranks, qoff)
