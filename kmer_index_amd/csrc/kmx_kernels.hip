@@ -3871,22 +3871,31 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
     // 1. count; the slot inside its bucket is all a position keeps (16 bits: two per register — the position itself is read
     //    again for the scatter, out of L2, and its bucket recomputed: registers are what this shape is short of)
     uint32_t slots[E / 2];
-    static_assert(E % 2 == 0, "two slots per register");
+    static_assert(E % 4 == 0, "two slots per register, four positions per load");
 #pragma unroll
-    for (int j2 = 0; j2 < E / 2; ++j2) {
-        uint32_t packed = 0;
+    for (int q4 = 0; q4 < E / 4; ++q4) {
+        // (four consecutive positions a thread and step as ONE 16-byte load — dword loads move at about 5 bytes per clock and CU; the
+        //  quad at the chunk's end is whole: the arena and the scratch buffer are padded)
+        const uint32_t i0 = uint32_t(q4) * 4u * THREADS + tid * 4u;
+        u32x4 v = {0, 0, 0, 0};
+        if (i0 < c_len) v = *reinterpret_cast<const u32x4_a4*>(seg + i0);
+        const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const uint32_t i = uint32_t(2 * j2 + h) * THREADS + tid;
-            uint32_t old = 0, sh = 0;
-            if (i < c_len) {
-                const uint32_t b = min(__umulhi(seg[i] - v_lo, mul), uint32_t(KMX_PBK_NB - 1));
-                sh = 16u * (b & 1u);
-                old = atomicAdd(&cnt[b >> 1], 1u << sh);
+        for (int h2 = 0; h2 < 2; ++h2) {
+            uint32_t packed = 0;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t i = i0 + uint32_t(2 * h2 + h);
+                uint32_t old = 0, sh = 0;
+                if (i < c_len) {
+                    const uint32_t b = min(__umulhi(pv[2 * h2 + h] - v_lo, mul), uint32_t(KMX_PBK_NB - 1));
+                    sh = 16u * (b & 1u);
+                    old = atomicAdd(&cnt[b >> 1], 1u << sh);
+                }
+                packed |= ((old >> sh) & 0xFFFFu) << (16 * h);
             }
-            packed |= ((old >> sh) & 0xFFFFu) << (16 * h);
+            slots[2 * q4 + h2] = packed;
         }
-        slots[j2] = packed;
     }
     __syncthreads();
     // 2. exclusive scan of the counts: thread t owns buckets [BPT t, BPT t + BPT)
@@ -3927,13 +3936,20 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
     __syncthreads();
     // 3. scatter
 #pragma unroll
-    for (int j = 0; j < E; ++j) {
-        const uint32_t i = uint32_t(j) * THREADS + tid;
-        if (i < c_len) {
-            const uint32_t p = seg[i];
-            const uint32_t b = min(__umulhi(p - v_lo, mul), uint32_t(KMX_PBK_NB - 1)), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
-            const uint32_t place = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
-            out[place + slot] = p;
+    for (int q4 = 0; q4 < E / 4; ++q4) {
+        const uint32_t i0 = uint32_t(q4) * 4u * THREADS + tid * 4u;
+        u32x4 v = {0, 0, 0, 0};
+        if (i0 < c_len) v = *reinterpret_cast<const u32x4_a4*>(seg + i0);
+        const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            const int j = 4 * q4 + h;
+            if (i0 + uint32_t(h) < c_len) {
+                const uint32_t p = pv[h];
+                const uint32_t b = min(__umulhi(p - v_lo, mul), uint32_t(KMX_PBK_NB - 1)), slot = (slots[j >> 1] >> (16 * (j & 1))) & 0xFFFFu;
+                const uint32_t place = (cnt[b >> 1] >> (16u * (b & 1u))) & 0xFFFFu;
+                out[place + slot] = p;
+            }
         }
     }
     __syncthreads();
@@ -4336,9 +4352,16 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const PsbItem*
 //                         chunk (occurrences that cluster), the slice handed back to the chunks (banded[i] = 0)
 //   k_prefix_split_scatter a block per tile again: positions binned by band in LDS, every bin appended to its band in `split`
 // ---------------------------------------------------------------------------
+#ifndef KMX_SPLIT
 #define KMX_SPLIT 24576            // positions per band aimed at (a band takes up to KMX_PSORT_BLOCK_CAP)
+#endif
 #define KMX_SPLIT_MAX 1024         // bands per slice at most (LDS histograms)
+#ifndef KMX_SPLIT_TILE
 #define KMX_SPLIT_TILE 8192        // positions per block of the count / scatter kernels
+#endif
+#ifndef KMX_SPLIT_SCATTER_THREADS
+#define KMX_SPLIT_SCATTER_THREADS 1024
+#endif
 struct PsbSplit {
     uint64_t src0;                 // the slice's first position in the arena
     uint64_t dst0;                 // ... in `out`
@@ -4365,7 +4388,12 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_count(const PsbSplit* 
     __shared__ uint32_t hist[KMX_SPLIT_MAX];
     const uint32_t tid = threadIdx.x;
     const uint64_t n_tiles = min((uint64_t)*n_tiles_p, cap_tiles);
-    for (uint64_t j = blockIdx.x; j < n_tiles; j += gridDim.x) {
+    // (tiles that run at the same time should be tiles of DIFFERENT slices: every tile of a slice claims room on the slice's band
+    //  cursors with atomics that return, and some two hundred tiles of one slice queueing on the same 64 addresses were what the
+    //  scatter waited for — the list holds a slice's tiles one behind the other, so it is walked with a large odd stride)
+    const uint64_t stride = n_tiles % 7919u ? 7919u : 7927u;
+    for (uint64_t j0 = blockIdx.x; j0 < n_tiles; j0 += gridDim.x) {
+        const uint64_t j = (j0 * stride) % n_tiles;
         const PsbTile t = tiles[j];
         if (t.split == 0xFFFFFFFFu) continue;                      // (block-uniform)
         const PsbSplit sp = splits[t.split];
@@ -4449,7 +4477,12 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
     __shared__ uint32_t wsum[THREADS / KMX_WAVE];
     const uint32_t tid = threadIdx.x, lane = tid & (KMX_WAVE - 1), wv = tid / KMX_WAVE;
     const uint64_t n_tiles = min((uint64_t)*n_tiles_p, cap_tiles);
-    for (uint64_t j = blockIdx.x; j < n_tiles; j += gridDim.x) {
+    // (tiles that run at the same time should be tiles of DIFFERENT slices: every tile of a slice claims room on the slice's band
+    //  cursors with atomics that return, and some two hundred tiles of one slice queueing on the same 64 addresses were what the
+    //  scatter waited for — the list holds a slice's tiles one behind the other, so it is walked with a large odd stride)
+    const uint64_t stride = n_tiles % 7919u ? 7919u : 7927u;
+    for (uint64_t j0 = blockIdx.x; j0 < n_tiles; j0 += gridDim.x) {
+        const uint64_t j = (j0 * stride) % n_tiles;
         const PsbTile t = tiles[j];
         if (t.split == 0xFFFFFFFFu) continue;                      // (block-uniform)
         const PsbSplit sp = splits[t.split];
@@ -4458,14 +4491,23 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
         for (uint32_t b = tid; b < KMX_SPLIT_MAX; b += THREADS) hist[b] = 0;
         __syncthreads();
         const uint32_t* __restrict__ seg = arena + sp.src0 + t0;
-        uint32_t val[PT], slot[PT];                                // a position and its number inside its band's share of the tile
+        // a position and its number inside its band's share of the tile.  Four consecutive positions a thread and step, as ONE 16-byte
+        // load (the arena is padded: the quad at the tile's end is whole) — dword loads move at about 5 bytes per clock and CU, and
+        // this kernel's loads, sorting and stores are phases of one block
+        static_assert(PT % 4 == 0, "whole quads");
+        uint32_t val[PT], slot[PT];
+#pragma unroll
+        for (uint32_t u = 0; u < PT; u += 4) {
+            const uint32_t e = (u * THREADS) + tid * 4;
+            if (e < n) {
+                const u32x4 v = *reinterpret_cast<const u32x4_a4*>(seg + e);
+                val[u] = v.x; val[u + 1] = v.y; val[u + 2] = v.z; val[u + 3] = v.w;
+            }
+        }
 #pragma unroll
         for (uint32_t u = 0; u < PT; ++u) {
-            const uint32_t e = u * THREADS + tid;
-            if (e < n) {
-                val[u] = seg[e];
-                slot[u] = atomicAdd(&hist[__umulhi(val[u], sp.mul)], 1u);
-            }
+            const uint32_t e = (u / 4) * 4 * THREADS + tid * 4 + (u & 3u);
+            if (e < n) slot[u] = atomicAdd(&hist[__umulhi(val[u], sp.mul)], 1u);
         }
         __syncthreads();
         {
@@ -4487,21 +4529,29 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
             for (uint32_t u = 0; u < BPT; ++u) {
                 const uint32_t b = tid * BPT + u;
                 hist[b] = first;
+#ifdef KMX_EXP_NO_GATOMIC
+                if (c[u]) gat[b] = counters[sp.cnt_at + sp.S + b] - first;
+#else
                 if (c[u]) gat[b] = counters[sp.cnt_at + sp.S + b] + atomicAdd(&counters[sp.cnt_at + 2 * sp.S + b], c[u]) - first;
+#endif
                 first += c[u];
             }
         }
         __syncthreads();
 #pragma unroll
         for (uint32_t u = 0; u < PT; ++u) {
-            const uint32_t e = u * THREADS + tid;
+            const uint32_t e = (u / 4) * 4 * THREADS + tid * 4 + (u & 3u);
             if (e < n) buf[hist[__umulhi(val[u], sp.mul)] + slot[u]] = val[u];
         }
         __syncthreads();
         uint32_t* __restrict__ to = split + sp.tmp0;
         for (uint32_t e = tid; e < n; e += THREADS) {              // (slot e of buf: consecutive slots of one band go to consecutive places)
             const uint32_t p = buf[e];
+#ifdef KMX_EXP_NO_STORE
+            if (gat[__umulhi(p, sp.mul)] + e == 0xFFFFFFFFu) to[0] = p;
+#else
             to[gat[__umulhi(p, sp.mul)] + e] = p;
+#endif
         }
         __syncthreads();
     }
@@ -4698,7 +4748,9 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_band(const PsbBand*
         }
         __syncthreads();
         {
-            // the gather: slot t of the band is entry t - bnd[r] of run r's piece (r advances with t: a thread's slots are THREADS apart)
+            // the gather: slot t of the band is entry t - bnd[r] of run r's piece (r advances with t: a thread's slots are THREADS apart).
+            // (four consecutive slots a thread as one 16-byte load where they lie in one piece, position by position across a piece's
+            //  end, was slower — 6.40 ms against 5.85 on 64 pieces of 95: nearly every wave has a lane at a piece's end every step)
             const uint32_t* __restrict__ seg = arena + b.src0;
             constexpr uint32_t PT = CAP / THREADS, GRP = 8;       // eight loads in flight per thread, then their eight LDS stores
             static_assert(PT % GRP == 0, "whole groups");
@@ -4780,8 +4832,8 @@ void launch_prefix_split(hipStream_t s, const PrefixSplitRoom& sr, const unsigne
     hipLaunchKernelGGL((k_prefix_split_count<256>), dim3(tb), dim3(256), 0, s, sp, tl, sr.cap_tiles, used + 5, arena, sr.counters);
     hipLaunchKernelGGL((k_prefix_split_scan<KMX_PSORT_BLOCK_CAP>), dim3(blocks_for(sr.cap_splits * KMX_WAVE, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s,
                        static_cast<PsbSplit*>(sr.splits), sr.cap_splits, used + 2, sr.counters, banded, n_text, static_cast<PsbItem*>(items), cap_items, n_other);
-    // (512 threads per tile: sixteen positions a thread — 24 waves per CU behind 44 KB of LDS a block instead of 12)
-    hipLaunchKernelGGL((k_prefix_split_scatter<512>), dim3(tb), dim3(512), 0, s, sp, tl, sr.cap_tiles, used + 5, arena, sr.counters, sr.scratch);
+    // (1024 threads per tile of 8192: eight positions a thread; measured against 256 / 512 threads and tiles of 2048 / 4096, tools/exp/r04_split_knobs.sh)
+    hipLaunchKernelGGL((k_prefix_split_scatter<KMX_SPLIT_SCATTER_THREADS>), dim3(tb), dim3(KMX_SPLIT_SCATTER_THREADS), 0, s, sp, tl, sr.cap_tiles, used + 5, arena, sr.counters, sr.scratch);
 }
 uint64_t prefix_split_bytes(int what) { return what == 0 ? sizeof(PsbSplit) : sizeof(PsbTile); }
 uint64_t prefix_split_target() { return KMX_SPLIT; }
