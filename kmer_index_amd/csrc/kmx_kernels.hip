@@ -3854,9 +3854,13 @@ typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
 // out: CAP words, cnt: NB / 2 words (two 16-bit counters per word), wsum: THREADS / 64 + 2 words.
 #define KMX_PBK_NB 8192
 #define KMX_PBK_GIVE_UP 48
-template <int THREADS, int CAP>
+// The chunk arrives in REGISTERS: quad q of thread t holds positions 4 (q THREADS + t) .. + 3 (k_prefix_sort_items asks for a chunk's
+// quads while the chunk before it is still being sorted).  after_scatter(): called by every thread once the quads have been read
+// for the last time — the caller refills them there.
+template <int THREADS, int CAP, typename After>
 __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wsum,
-                                                    const uint32_t* __restrict__ seg, uint32_t c_len, uint32_t v_lo, uint64_t v_width, uint32_t tid)
+                                                    const u32x4 (&quads)[CAP / THREADS / 4], uint32_t c_len, uint32_t v_lo, uint64_t v_width, uint32_t tid,
+                                                    After after_scatter)
 {
     // (the positions lie in [v_lo, v_lo + v_width): the whole text for a chunk of a slice, a band's stretch of it for a band
     //  of k_prefix_split_*)
@@ -3868,17 +3872,14 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
     for (uint32_t i = tid; i < KMX_PBK_NB / 2; i += THREADS) cnt[i] = 0;
     if (tid == 0) wsum[THREADS / 64] = 0;                         // the longest bucket
     __syncthreads();
-    // 1. count; the slot inside its bucket is all a position keeps (16 bits: two per register — the position itself is read
-    //    again for the scatter, out of L2, and its bucket recomputed: registers are what this shape is short of)
+    // 1. count; the slot inside its bucket is all a position keeps (16 bits: two per register; its bucket is recomputed for the
+    //    scatter)
     uint32_t slots[E / 2];
     static_assert(E % 4 == 0, "two slots per register, four positions per load");
 #pragma unroll
     for (int q4 = 0; q4 < E / 4; ++q4) {
-        // (four consecutive positions a thread and step as ONE 16-byte load — dword loads move at about 5 bytes per clock and CU; the
-        //  quad at the chunk's end is whole: the arena and the scratch buffer are padded)
         const uint32_t i0 = uint32_t(q4) * 4u * THREADS + tid * 4u;
-        u32x4 v = {0, 0, 0, 0};
-        if (i0 < c_len) v = *reinterpret_cast<const u32x4_a4*>(seg + i0);
+        const u32x4 v = quads[q4];
         const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2) {
@@ -3938,8 +3939,7 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
 #pragma unroll
     for (int q4 = 0; q4 < E / 4; ++q4) {
         const uint32_t i0 = uint32_t(q4) * 4u * THREADS + tid * 4u;
-        u32x4 v = {0, 0, 0, 0};
-        if (i0 < c_len) v = *reinterpret_cast<const u32x4_a4*>(seg + i0);
+        const u32x4 v = quads[q4];
         const uint32_t pv[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
@@ -3952,6 +3952,7 @@ __device__ __forceinline__ bool distribute_sort_lds(uint32_t* __restrict__ out, 
             }
         }
     }
+    after_scatter();
     __syncthreads();
     // 4. every bucket in order (a thread's BPT buckets are its own: no barrier between them)
 #pragma unroll 1
@@ -3995,15 +3996,8 @@ __device__ __forceinline__ void psb_chunk(uint32_t* __restrict__ sbuf, uint32_t*
 {
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
     const bool merge = Rc <= RUNS;
-    if constexpr (!MID) if (!merge) {
-        // more runs than the merge takes: the distribution sort (it gives up on a repeat of the text: the network below)
-        __shared__ uint32_t wsum[THREADS / 64 + 2];
-        if (distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, seg, c_len, v_lo, v_width, tid)) {
-            for (uint32_t t = tid; t < c_len; t += THREADS) dst[t] = sbuf[t];
-            __syncthreads();
-            return;
-        }
-    }
+    static_assert(MID, "the 1024-thread shape has kernels of its own (k_prefix_merge_block, k_prefix_sort_items)");
+    (void)v_lo; (void)v_width;
     if (merge && tid <= Rc) {
         const uint32_t o = runs[tid];
         bnd[tid] = o <= base ? 0u : min(o - base, c_len);
@@ -4325,17 +4319,92 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const PsbItem*
 {
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
     extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS + the distribution sort's counters
-    __shared__ uint32_t bnd[RUNS + 1];
-    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];
-    const uint64_t n_items = min((uint64_t)*n_items_p, cap_items);
-    for (uint64_t j = blockIdx.x; j < n_items; j += gridDim.x) {
-        const PsbItem it = items[cap_items - 1 - j];
-        uint32_t* dst = (it.dst & KMX_PSB_TMP) ? tmp + (it.dst & ~KMX_PSB_TMP) : out + it.dst;
-        const uint32_t* seg = (it.seg & KMX_PSB_TMP) ? split + (it.seg & ~KMX_PSB_TMP) : arena + it.seg;
-        const uint32_t c_len = it.len_runs & 0xFFFFu;
+    __shared__ uint32_t wsum[THREADS / 64 + 2];
+    constexpr uint32_t QPT = CAP / 4 / THREADS;                    // quads per thread
+    const uint32_t tid = threadIdx.x;
+    const uint64_t n_items = min((uint64_t)*n_items_p, cap_items), G = gridDim.x;
+    uint64_t j = blockIdx.x;
+    if (j >= n_items) return;
+    struct Hdr { const uint32_t* seg; uint32_t* dst; uint32_t c_len, v_lo; uint64_t v_width; };
+    auto header = [&](uint64_t jj) {
+        const PsbItem it = items[cap_items - 1 - jj];              // (the same in every lane)
+        Hdr h;
+        h.dst = (it.dst & KMX_PSB_TMP) ? tmp + (it.dst & ~KMX_PSB_TMP) : out + it.dst;
+        h.seg = (it.seg & KMX_PSB_TMP) ? split + (it.seg & ~KMX_PSB_TMP) : arena + it.seg;
+        h.c_len = it.len_runs & 0xFFFFu;
         const uint64_t range = reinterpret_cast<uintptr_t>(it.runs);            // v_lo | v_width << 32 (k_prefix_items, k_prefix_split_scan)
-        // (the run count of such a chunk is only known to be beyond RUNS: the record holds min(runs, 0xFFFF))
-        psb_chunk<THREADS, CAP, RUNS, false>(sbuf, bnd, ptab, seg, dst, nullptr, it.base, c_len, 0xFFFFu, uint32_t(range), range >> 32, threadIdx.x);
+        h.v_lo = uint32_t(range); h.v_width = range >> 32;
+        return h;
+    };
+    // A 148-KB block owns its CU alone: the next chunk's positions are asked for (16-byte loads: the arena and the scratch buffer are
+    // padded, the quad at a chunk's end is whole) as soon as this chunk's have been read for the last time, and arrive under its
+    // bucket sorts and its copy-out.
+    auto tq4 = [&] { uint32_t x = tid * 4; asm volatile("" : "+v"(x)); return x; };
+    u32x4 v[QPT];
+    auto ask = [&](const Hdr& h) {
+        const uint32_t tq = tq4();
+#pragma unroll
+        for (uint32_t q = 0; q < QPT; ++q)
+            if (tq + q * THREADS * 4 < h.c_len) v[q] = *reinterpret_cast<const u32x4_a4*>(h.seg + tq + q * THREADS * 4);
+    };
+    Hdr cur = header(j);
+    ask(cur);
+    for (;;) {
+        const bool more = j + G < n_items;                         // block-uniform
+        Hdr nxt = cur;
+        nxt.c_len = 0;
+        if (more) nxt = header(j + G);
+        const bool sorted = distribute_sort_lds<THREADS, CAP>(sbuf, sbuf + Shape::WORDS, wsum, v, cur.c_len, cur.v_lo, cur.v_width, tid, [&] { ask(nxt); });
+        if (!sorted) {
+            // positions that crowd (a repeat of the text): the bitonic network over the chunk, padded to a power of two
+            uint32_t n2 = 2;
+            while (n2 < cur.c_len) n2 <<= 1;
+            const uint32_t tq = tq4();
+#pragma unroll
+            for (uint32_t q = 0; q < QPT; ++q) {
+                const uint32_t t = tq + q * THREADS * 4;
+                if (t < n2) {
+                    u32x4 w = v[q];
+                    w.x = t + 0 < cur.c_len ? w.x : 0xFFFFFFFFu;
+                    w.y = t + 1 < cur.c_len ? w.y : 0xFFFFFFFFu;
+                    w.z = t + 2 < cur.c_len ? w.z : 0xFFFFFFFFu;
+                    w.w = t + 3 < cur.c_len ? w.w : 0xFFFFFFFFu;
+                    *reinterpret_cast<u32x4*>(sbuf + t) = w;
+                }
+            }
+            ask(nxt);
+            __syncthreads();
+            bitonic_lds(sbuf, n2, tid, uint32_t(THREADS), [] { __syncthreads(); });
+        }
+        {
+            const uint32_t tq = tq4();
+            const int32_t left = int32_t(cur.c_len) - int32_t(tq);
+            const uint32_t* __restrict__ from = sbuf + tq;
+            uint32_t* __restrict__ to = cur.dst + tq;
+#pragma unroll
+            for (uint32_t h0 = 0; h0 < QPT; h0 += QPT / 2) {
+                u32x4 w[QPT / 2];
+#pragma unroll
+                for (uint32_t u = 0; u < QPT / 2; ++u)
+                    if (left > int32_t((h0 + u) * THREADS * 4)) w[u] = *reinterpret_cast<const u32x4*>(from + (h0 + u) * THREADS * 4);
+#pragma unroll
+                for (uint32_t u = 0; u < QPT / 2; ++u) {
+                    const int32_t l = left - int32_t((h0 + u) * THREADS * 4);
+                    uint32_t* __restrict__ o = to + (h0 + u) * THREADS * 4;
+                    if (l > 3) {
+                        *reinterpret_cast<u32x4_a4*>(o) = w[u];
+                    } else if (l > 0) {
+                        o[0] = w[u].x;
+                        if (l > 1) o[1] = w[u].y;
+                        if (l > 2) o[2] = w[u].z;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (!more) break;
+        cur = nxt;
+        j += G;
     }
 }
 
