@@ -15,8 +15,15 @@
 //   k_fill          output-centric copy of bucket runs -> to_vector() lists
 //  [k_compact]      STITCH fallback without a survivor buffer: mask-word decode, popcount prefix compaction
 //  [k_prefix_*]     PREFIX slices of several runs: merged into one ascending list (the std::sort of
-//                   kmer_index_result.hpp:258) — k_prefix_sort_small / k_prefix_merge_small / k_prefix_sort_block /
-//                   k_prefix_merge_pass by slice length; slices of one run (prefix levels) need none of them
+//                   kmer_index_result.hpp:258); slices of one run (prefix levels) need none of them.  By slice length and runs:
+//                     <= 2048 positions        a wave per slice: k_prefix_sort_small / k_prefix_merge_small
+//                     <= 8192                  a 256-thread block per slice: k_prefix_sort_block
+//                     <= 32768 (one chunk)     records from k_prefix_items; k_prefix_merge_block (<= 128 runs: merge rounds in LDS, the
+//                                              next chunk's loads and the previous chunk's stores under them) or k_prefix_sort_items
+//                                              (more runs: distribution sort)
+//                     beyond, <= 64 runs       cut by value into bands (k_prefix_bands), a 256-thread block per band (k_prefix_merge_band)
+//                     beyond, more runs        spread by value (k_prefix_split_count / _scan / _scatter), a band per k_prefix_sort_items block
+//                     beyond, positions that crowd   chunks + k_prefix_merge_pass, ceil(log2 chunks) times
 //  [k_validate_wide / k_validate_more_thread]  long filter buckets (linear intersection) / few further parts per query
 //
 // All arithmetic is unsigned integer; no MFMA.  The kernels are HBM / latency
@@ -3280,6 +3287,26 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_len(QueryDesc d, uint64_t 
     plen[i] = (len > KMX_PSORT_BLOCK_CAP && d.c0[q] >= 2 && !banded[i]) ? (len + KMX_PM_TILE - 1) / KMX_PM_TILE : 0u;
 }
 
+// What the wave-per-slice kernels need to know about a listed PREFIX query before they can ask for its positions — six loads that
+// depend on the list entry.  k_prefix_sort_small walks its share of the list with these a step ahead (and the list entry two): a slice of
+// a few hundred positions used to start behind the whole chain of round trips (list entry -> descriptor -> planner -> offset table) — 7 % of
+// the kernel on 381-position slices; k_prefix_merge_small, whose rounds are most of its time, gained nothing from the same.
+struct PrefixHead {
+    uint32_t R, len;
+    uint64_t src, hoff, m, key;
+};
+__device__ __forceinline__ PrefixHead prefix_head(const QueryDesc& d, const uint64_t* __restrict__ qoff, const uint64_t* __restrict__ hit_off, uint32_t q)
+{
+    PrefixHead h;
+    h.R = d.c0[q];
+    h.len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    h.src = d.src[q] & ~SRC_FLAGS;
+    h.hoff = hit_off[q];
+    h.m = qoff[q + 1] - qoff[q];
+    h.key = d.key[q];
+    return h;
+}
+
 // PREFIX queries with a short slice (<= KMX_PSORT_CAP positions), one wave per query.  The slice is the concatenation of
 // R ascending runs (one per key of the prefix range) and is read where it lies in the arena (k_fill leaves the slots of
 // a slice with two or more runs alone); what leaves for `out` is ascending — the std::sort of kmer_index_result.hpp:258.
@@ -3297,15 +3324,20 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_sort_small(const KmxIndexD
     const uint32_t lane = lane_id(), wv = threadIdx.x / KMX_WAVE;
     const uint64_t wave = (uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x) / KMX_WAVE;
     const uint64_t n_waves = uint64_t(gridDim.x) * (KMX_BLOCK / KMX_WAVE);
+    if (wave >= n_prefix) return;
+    uint32_t q_ahead = d.prefix_list[wave];
+    PrefixHead h_ahead = prefix_head(d, qoff, hit_off, q_ahead);
+    q_ahead = wave + n_waves < n_prefix ? d.prefix_list[wave + n_waves] : 0u;
     for (uint64_t i = wave; i < n_prefix; i += n_waves) {
-        const uint32_t q = d.prefix_list[i];
-        const uint32_t R = d.c0[q];
-        const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+        const PrefixHead hd = h_ahead;                                  // this slice's (asked for a step ago)
+        if (i + n_waves < n_prefix) h_ahead = prefix_head(d, qoff, hit_off, q_ahead);     // the next slice's, its list entry having arrived
+        if (i + 2 * n_waves < n_prefix) q_ahead = d.prefix_list[i + 2 * n_waves];
+        const uint32_t R = hd.R, len = hd.len;
         if (!KMX_PSORT_IS_SMALL(R, len) || KMX_PSORT_IS_MERGE(R, len) || R < 2 || len < 2) continue;   // wave-uniform
-        const uint32_t* __restrict__ srcp = arena + (d.src[q] & ~SRC_FLAGS);
-        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);
+        const uint32_t* __restrict__ srcp = arena + hd.src;
+        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, hd.m, hd.key);
         if (lane <= min(R, uint32_t(KMX_PSORT_MAX_RUNS))) bnd[wv][lane] = offs[lane] - offs[0];
-        uint32_t* __restrict__ seg = out + hit_off[q];
+        uint32_t* __restrict__ seg = out + hd.hoff;
         auto wsync = [] {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -4598,11 +4630,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
             for (uint32_t u = 0; u < BPT; ++u) {
                 const uint32_t b = tid * BPT + u;
                 hist[b] = first;
-#ifdef KMX_EXP_NO_GATOMIC
-                if (c[u]) gat[b] = counters[sp.cnt_at + sp.S + b] - first;
-#else
                 if (c[u]) gat[b] = counters[sp.cnt_at + sp.S + b] + atomicAdd(&counters[sp.cnt_at + 2 * sp.S + b], c[u]) - first;
-#endif
                 first += c[u];
             }
         }
@@ -4616,11 +4644,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
         uint32_t* __restrict__ to = split + sp.tmp0;
         for (uint32_t e = tid; e < n; e += THREADS) {              // (slot e of buf: consecutive slots of one band go to consecutive places)
             const uint32_t p = buf[e];
-#ifdef KMX_EXP_NO_STORE
-            if (gat[__umulhi(p, sp.mul)] + e == 0xFFFFFFFFu) to[0] = p;
-#else
             to[gat[__umulhi(p, sp.mul)] + e] = p;
-#endif
         }
         __syncthreads();
     }
