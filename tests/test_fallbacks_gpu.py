@@ -91,3 +91,54 @@ def test_chunked_search_survives_an_out_of_memory_with_one_worker():
         assert res.returncode == 0 and "oom child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
         outs.append(res.stdout.strip().splitlines()[-1].split()[3:])
     assert outs[0] == outs[1] == outs[2], outs           # same number of chunks (no halving), same hits
+
+
+SUBK_CHILD = r"""
+import sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+from kmer_index_amd import engine, synth
+from oracle import orc
+from tests.helpers import pack
+
+text = synth.ranks(606, 900_000, 4)
+for ks in ([10], [6]):
+    idx = engine.Index(text, 4, ks, prefix_levels=-1)
+    oidx = orc.Index(text, 4, ks)
+    k = ks[0]
+    # k = 10: m = 2 .. 5 -> 56 K .. 879 positions in 65536 .. 1024 runs; k = 6: m = 1 .. 3 -> 225 K .. 14 K positions in 1024 .. 64 runs
+    lens = (2, 3, 4, 5) if k == 10 else (1, 2, 3)
+    qs = [text[s0:s0 + m].copy() for m in lens for s0 in (1000, 5003, 70001)]
+    qs += [text[text.size - m:].copy() for m in lens]
+    qranks, qoff = pack(qs)
+    idx.stats_enable(True)
+    res = engine.Result()
+    for rep in range(2):
+        ho, pos, st, kd = idx.search(qranks, qoff, result=res).host()
+        o_off, o_pos, o_st, _ = oidx.search_batch(qranks, qoff, n_threads=4)
+        assert np.array_equal(st, o_st.astype(np.uint8)), (ks, rep)
+        assert np.array_equal(ho, o_off) and np.array_equal(pos, o_pos), (ks, rep)
+    st = idx.stats()
+    print("stats", ks, {n: v["launches"] for n, v in st.items() if n.startswith("k_prefix") and v["launches"]})
+    idx.close()
+print("subk child ok")
+"""
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env,ran,not_ran", [({}, ("k_prefix_split", "k_prefix_bands"), ()),
+                                             ({"KMX_NO_SPLIT": "1"}, ("k_prefix_bands", "k_prefix_merge_pass"), ("k_prefix_split",)),
+                                             ({"KMX_NO_BANDS": "1"}, ("k_prefix_merge_pass",), ("k_prefix_split", "k_prefix_bands"))])
+def test_subk_slices_beyond_a_chunk_without_bands_or_splits(env, ran, not_ran):
+    """The sub-k slices beyond one chunk go through value bands (few runs) or are spread by value (many runs); chunks + merge passes are
+    what remains for positions that crowd — and for KMX_NO_SPLIT / KMX_NO_BANDS (read once per process: a child each), which keep that
+    path alive under the same oracle comparison."""
+    e = dict(os.environ)
+    e.update(env)
+    res = subprocess.run([sys.executable, "-c", SUBK_CHILD % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=e)
+    assert res.returncode == 0 and "subk child ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+    stats = " ".join(line for line in res.stdout.splitlines() if line.startswith("stats"))
+    for name in ran:
+        assert f"'{name}'" in stats, (name, stats)
+    for name in not_ran:
+        assert f"'{name}'" not in stats, (name, stats)
