@@ -232,7 +232,7 @@ struct kmx_result {
     uint64_t n_mask_words = 0;
     // device
     DevBuf src, cnt, c0, aux, key, p1, kind, status, stitch_list, prefix_list, short_list, hit_off, bsum, ctr, tile_q, out,
-        mask_words, stitch_hits, plen, poff, ptmp, pitems, pbands, pcuts, pbanded, psplits, ptiles, pscnt, pscratch, in_qranks, in_qoff;
+        mask_words, stitch_hits, plen, poff, ptmp, pitems, pbands, pcuts, pbanded, psplits, ptiles, pscnt, pscratch, pmid, in_qranks, in_qoff;
     unsigned long long* h_ctr = nullptr;   // pinned
     // host mirrors
     HostBuf h_hit_off, h_positions, h_status, h_kinds, h_mask_base, h_mask_words, h_cand_count, h_cand_src, h_small;
@@ -274,7 +274,7 @@ struct kmx_result {
     {
         size_t b = 0;
         for (const DevBuf* d : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &short_list, &hit_off, &bsum, &ctr,
-                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &psplits, &ptiles, &pscnt, &pscratch, &in_qranks, &in_qoff, &small_xchg})
+                                &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &psplits, &ptiles, &pscnt, &pscratch, &pmid, &in_qranks, &in_qoff, &small_xchg})
             b += d->cap;
         return b;
     }
@@ -282,7 +282,7 @@ struct kmx_result {
     void release()
     {
         for (DevBuf* b : {&src, &cnt, &c0, &aux, &key, &p1, &kind, &status, &stitch_list, &prefix_list, &short_list, &hit_off, &bsum, &ctr,
-                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &psplits, &ptiles, &pscnt, &pscratch, &in_qranks, &in_qoff, &small_xchg})
+                          &tile_q, &out, &mask_words, &stitch_hits, &plen, &poff, &ptmp, &pitems, &pbands, &pcuts, &pbanded, &psplits, &ptiles, &pscnt, &pscratch, &pmid, &in_qranks, &in_qoff, &small_xchg})
             b->release();
         for (HostBuf* b : {&h_hit_off, &h_positions, &h_status, &h_kinds, &h_mask_base, &h_mask_words, &h_cand_count, &h_cand_src, &h_small, &mailbox, &small_in})
             b->release();
@@ -1719,10 +1719,11 @@ static kmx_status search_finish(kmx_result* r)
                 kmx::launch_scan(s, r->plen.as<uint32_t>(), np, r->bsum.as<uint64_t>(), r->poff.as<uint64_t>(), ctr + KMX_CTR_PREFIX_TOTAL);
             });
         }
+        if (n_mid) HIP_TRY(r->pmid.ensure(np * kmx::prefix_item_bytes()));
         timed(ix, K_PREFIX_SORT_BLOCK, s, [&] {
             kmx::launch_prefix_sort_block(s, dix, qo, d_big, np, n_mid, hit_off, ix->d_arena, out, large ? r->poff.as<uint64_t>() : nullptr,
                                           large ? r->ptmp.as<uint32_t>() : nullptr, r->pitems.p, cap_items, ctr + KMX_CTR_PSB_MERGE,
-                                          r->pbanded.as<uint32_t>(), r->pbands.p, cap_bands, r->pcuts.as<uint32_t>(), ctr + KMX_CTR_PSB_BANDS, sr.scratch, ix->d_dbg);
+                                          r->pbanded.as<uint32_t>(), r->pbands.p, cap_bands, r->pcuts.as<uint32_t>(), ctr + KMX_CTR_PSB_BANDS, sr.scratch, r->pmid.p, ix->h_header.n, ix->d_dbg);
         });
         if (large) {
             uint32_t passes = 0;

@@ -128,11 +128,13 @@ uint64_t prefix_split_target();
 uint64_t prefix_split_tile();
 // items: room for cap_items records of prefix_item_bytes() each, cap_items >= (listed slices beyond KMX_PSORT_MID_CAP) + (positions of the
 // slices beyond KMX_PSORT_BLOCK_CAP) / KMX_PSORT_BLOCK_CAP; n_items: two zeroed device counters (KMX_CTR_PSB_MERGE, KMX_CTR_PSB_OTHER);
-// banded / bands / cuts / n_bands: what launch_prefix_bands left; dbg: the index's debug words
+// banded / bands / cuts / n_bands: what launch_prefix_bands left; split: the scratch buffer of launch_prefix_split; mid_items: n_prefix records of
+// prefix_item_bytes() (only when n_mid > 0); dbg: the index's debug words
 void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp,
                               void* items, uint64_t cap_items, unsigned long long* n_items, const uint32_t* banded, const void* bands, uint64_t cap_bands,
-                              const uint32_t* cuts, const unsigned long long* n_bands, const uint32_t* split, unsigned long long* dbg);
+                              const uint32_t* cuts, const unsigned long long* n_bands, const uint32_t* split, void* mid_items, uint64_t n_text,
+                              unsigned long long* dbg);
 uint64_t prefix_item_bytes();
 uint64_t prefix_band_target();
 uint64_t prefix_band_runs();

@@ -4091,30 +4091,6 @@ __device__ __forceinline__ void psb_chunk(uint32_t* __restrict__ sbuf, uint32_t*
     __syncthreads();
 }
 
-// The 256-thread shape: slices of at most KMX_PSORT_MID_CAP positions (one chunk each), a block per slice, four blocks per CU.
-template <int THREADS, int CAP, int RUNS>
-__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_block(const KmxIndexDev* __restrict__ ix,
-                                                                const uint64_t* __restrict__ qoff, QueryDesc d,
-                                                                uint64_t n_prefix,
-                                                                const uint64_t* __restrict__ hit_off,
-                                                                const uint32_t* __restrict__ arena,
-                                                                uint32_t* __restrict__ out)
-{
-    typedef PsbShape<THREADS, CAP, RUNS> Shape;
-    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
-    __shared__ uint32_t bnd[RUNS + 1];
-    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
-    const uint32_t tid = threadIdx.x;
-    for (uint64_t i = blockIdx.x; i < n_prefix; i += gridDim.x) {
-        const uint32_t q = d.prefix_list[i];
-        const uint32_t R = d.c0[q];
-        const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-        if (len > CAP) continue;                                                          // the 1024-thread kernels' (block-uniform)
-        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);   // R + 1 run boundaries
-        psb_chunk<THREADS, CAP, RUNS, true>(sbuf, bnd, ptab, arena + (d.src[q] & ~SRC_FLAGS), out + hit_off[q], offs, offs[0], len, R, 0u, ix->n, tid);
-    }
-}
-
 // The chunks of the longer slices (up to KMX_PSORT_BLOCK_CAP positions each) as ITEMS: what a 1024-thread block needs to know about
 // one chunk, in one 32-byte record — written once by k_prefix_items (a wave per slice, a lane per chunk), so that the blocks
 // that do the work find a chunk's header with ONE load asked for two chunks ahead instead of five dependent round trips (list
@@ -4130,6 +4106,52 @@ struct PsbItem {
 };
 static_assert(sizeof(PsbItem) == 32, "one record = two 16-byte loads");
 #define KMX_PSB_TMP (1ull << 63)
+
+// The 256-thread shape: slices of at most KMX_PSORT_MID_CAP positions (one chunk each), a block per slice, four blocks per CU — from
+// records as well (k_prefix_mid_items: a thread per listed slice, record i for list entry i, length 0 = not this shape's): a slice
+// of six thousand positions took about as long to FIND (list entry -> descriptor -> planner -> offset table: five dependent round
+// trips) as to merge; the record is one load, asked for a slice ahead.
+__global__ __launch_bounds__(KMX_BLOCK) void k_prefix_mid_items(const KmxIndexDev* __restrict__ ix, const uint64_t* __restrict__ qoff, QueryDesc d,
+                                                                uint64_t n_prefix, const uint64_t* __restrict__ hit_off, PsbItem* __restrict__ items)
+{
+    const uint64_t i = uint64_t(blockIdx.x) * KMX_BLOCK + threadIdx.x;
+    if (i >= n_prefix) return;
+    const uint32_t q = d.prefix_list[i];
+    const uint32_t R = d.c0[q];
+    const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
+    PsbItem it;
+    it.seg = 0; it.dst = 0; it.runs = nullptr; it.len_runs = 0; it.base = 0;
+    if (len <= KMX_PSORT_MID_CAP) {
+        const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);   // R + 1 run boundaries
+        it.seg = d.src[q] & ~SRC_FLAGS;
+        it.dst = hit_off[q];
+        it.runs = (const uint32_t*)offs;
+        it.len_runs = len | (min(R, 0xFFFFu) << 16);
+        it.base = offs[0];
+    }
+    items[i] = it;
+}
+
+template <int THREADS, int CAP, int RUNS>
+__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_block(const PsbItem* __restrict__ items, uint64_t n_prefix, uint64_t n_text,
+                                                                const uint32_t* __restrict__ arena, uint32_t* __restrict__ out)
+{
+    typedef PsbShape<THREADS, CAP, RUNS> Shape;
+    extern __shared__ __attribute__((aligned(16))) uint32_t sbuf[];             // Shape::WORDS
+    __shared__ uint32_t bnd[RUNS + 1];
+    __shared__ uint32_t ptab[Shape::ROUNDS * Shape::TSTRIDE];      // the pair tables of every round
+    const uint32_t tid = threadIdx.x;
+    uint64_t i = blockIdx.x;
+    if (i >= n_prefix) return;
+    PsbItem ahead = items[i];
+    for (; i < n_prefix; i += gridDim.x) {
+        const PsbItem it = ahead;
+        if (i + gridDim.x < n_prefix) ahead = items[i + gridDim.x];                      // (the same in every lane; used a slice later)
+        const uint32_t len = it.len_runs & 0xFFFFu;
+        if (len == 0) continue;                                                          // another shape's (block-uniform)
+        psb_chunk<THREADS, CAP, RUNS, true>(sbuf, bnd, ptab, arena + it.seg, out + it.dst, as_global(it.runs), it.base, len, it.len_runs >> 16, 0u, n_text, tid);
+    }
+}
 
 template <int CAP, int RUNS>
 __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_items(const KmxIndexDev* __restrict__ ix, const uint64_t* __restrict__ qoff, QueryDesc d,
@@ -4938,13 +4960,16 @@ uint64_t prefix_split_tile() { return KMX_SPLIT_TILE; }
 void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64_t* qoff, const QueryDesc& d, uint64_t n_prefix, uint64_t n_mid,
                               const uint64_t* hit_off, const uint32_t* arena, uint32_t* out, const uint64_t* tile_off, uint32_t* tmp,
                               void* items, uint64_t cap_items, unsigned long long* n_items, const uint32_t* banded, const void* bands, uint64_t cap_bands,
-                              const uint32_t* cuts, const unsigned long long* n_bands, const uint32_t* split, unsigned long long* dbg)
+                              const uint32_t* cuts, const unsigned long long* n_bands, const uint32_t* split, void* mid_items, uint64_t n_text,
+                              unsigned long long* dbg)
 {
     if (n_mid) {
+        PsbItem* mi = static_cast<PsbItem*>(mid_items);
+        hipLaunchKernelGGL(k_prefix_mid_items, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, mi);
         auto fn = k_prefix_sort_block<256, KMX_PSORT_MID_CAP, 64>;
         const size_t lds = size_t(PsbMid::WORDS) * 4;
         const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 16);
-        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(256), lds, s, ix, qoff, d, n_prefix, hit_off, arena, out);
+        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(256), lds, s, mi, n_prefix, n_text, arena, out);
     }
     if (n_prefix > n_mid) {
         {

@@ -11,7 +11,7 @@ import torch  # noqa: E402
 from kmer_index_amd import engine, synth  # noqa: E402
 
 n, sigma, k = 100_000_000, 4, 10
-CASES = ((9, 2_000_000), (8, 1_000_000), (6, 50_000), (5, 10_000), (3, 300), (13, 2_000_000), (25, 2_000_000),
+CASES = ((9, 2_000_000), (8, 1_000_000), (7, 200_000), (6, 50_000), (5, 10_000), (3, 300), (13, 2_000_000), (25, 2_000_000),
          (20, 2_000_000), (30, 2_000_000), (100, 2_000_000), (150, 1_000_000), (1000, 100_000), (5000, 20_000))
 if os.environ.get("KMX_PROBE") == "aa20":       # BASELINE configs[4]'s index: 20 letters, k = 5, buckets of about 3
     n, sigma, k = 10_000_000, 20, 5
