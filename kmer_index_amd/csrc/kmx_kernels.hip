@@ -105,6 +105,17 @@ __device__ __forceinline__ const KMX_GLOBAL T* as_global(const T* p)
 typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+// a quad of sorted positions on its way out (the sub-k kernels' copy-outs): streamed, nothing on the device reads it again soon
+#ifdef KMX_NT_QUAD_LOADS
+#define KMX_LOAD_QUAD(p) __builtin_nontemporal_load(reinterpret_cast<const u32x4_a4*>(p))
+#else
+#define KMX_LOAD_QUAD(p) (*reinterpret_cast<const u32x4_a4*>(p))
+#endif
+#ifdef KMX_PLAIN_QUAD_STORES
+#define KMX_STORE_QUAD(p, q) (*reinterpret_cast<u32x4_a4*>(p) = (q))
+#else
+#define KMX_STORE_QUAD(p, q) __builtin_nontemporal_store((q), reinterpret_cast<u32x4_a4*>(p))
+#endif
 
 // plan[m] as one 32-bit load ({u8 scheme, u8 elem, u16 nparts}, little endian).
 // plan_effective: the entry a query of m letters is ANSWERED by — a KMX_SCHEME_REPLANNED entry (engine planner table) reads
@@ -4047,7 +4058,7 @@ __device__ __forceinline__ void psb_chunk(uint32_t* __restrict__ sbuf, uint32_t*
         for (uint32_t u = 0; u < QPT; ++u) {
             const uint32_t t = (u * THREADS + tid) * 4;
             if (t + 3 < c_len) {
-                v[u] = *reinterpret_cast<const u32x4_a4*>(seg + t);
+                v[u] = KMX_LOAD_QUAD(seg + t);
             } else {
                 v[u].x = t + 0 < c_len ? seg[t + 0] : 0xFFFFFFFFu;
                 v[u].y = t + 1 < c_len ? seg[t + 1] : 0xFFFFFFFFu;
@@ -4080,7 +4091,7 @@ __device__ __forceinline__ void psb_chunk(uint32_t* __restrict__ sbuf, uint32_t*
         for (uint32_t u = 0; u < QPT; ++u) {
             const uint32_t t = (u * THREADS + tid) * 4;
             if (t + 3 < c_len) {
-                *reinterpret_cast<u32x4_a4*>(dst + t) = v[u];
+                KMX_STORE_QUAD(dst + t, v[u]);
             } else if (t < c_len) {
                 dst[t] = v[u].x;
                 if (t + 1 < c_len) dst[t + 1] = v[u].y;
@@ -4259,7 +4270,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem
     // is staged) — a branch for that thread with loads of its own would put a wait for ALL of the wave's loads into this place
     auto ask = [&](const Hdr& h, u32x4& q, uint32_t k) {
         const uint32_t t = tq4() + k * THREADS * 4;
-        if (t < h.c_len) q = *reinterpret_cast<const u32x4_a4*>(h.seg + t);
+        if (t < h.c_len) q = KMX_LOAD_QUAD(h.seg + t);
     };
     // quad k of a sorted chunk to where the chunk goes
     auto give = [&](const Hdr& h, const u32x4& q, uint32_t k) {
@@ -4267,7 +4278,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_block(const PsbItem
         const int32_t l = int32_t(h.c_len) - int32_t(t);
         uint32_t* __restrict__ o = h.dst + t;
         if (l > 3) {
-            *reinterpret_cast<u32x4_a4*>(o) = q;
+            KMX_STORE_QUAD(o, q);
         } else if (l > 0) {
             o[0] = q.x;
             if (l > 1) o[1] = q.y;
@@ -4399,7 +4410,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const PsbItem*
         const uint32_t tq = tq4();
 #pragma unroll
         for (uint32_t q = 0; q < QPT; ++q)
-            if (tq + q * THREADS * 4 < h.c_len) v[q] = *reinterpret_cast<const u32x4_a4*>(h.seg + tq + q * THREADS * 4);
+            if (tq + q * THREADS * 4 < h.c_len) v[q] = KMX_LOAD_QUAD(h.seg + tq + q * THREADS * 4);
     };
     Hdr cur = header(j);
     ask(cur);
@@ -4446,7 +4457,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const PsbItem*
                     const int32_t l = left - int32_t((h0 + u) * THREADS * 4);
                     uint32_t* __restrict__ o = to + (h0 + u) * THREADS * 4;
                     if (l > 3) {
-                        *reinterpret_cast<u32x4_a4*>(o) = w[u];
+                        KMX_STORE_QUAD(o, w[u]);
                     } else if (l > 0) {
                         o[0] = w[u].x;
                         if (l > 1) o[1] = w[u].y;
@@ -4906,7 +4917,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_band(const PsbBand*
             for (uint32_t u = 0; u < QPT; ++u) {
                 const uint32_t t = (u * THREADS + tid) * 4;
                 if (t + 3 < len) {
-                    *reinterpret_cast<u32x4_a4*>(dst + t) = v[u];
+                    KMX_STORE_QUAD(dst + t, v[u]);
                 } else if (t < len) {
                     dst[t] = v[u].x;
                     if (t + 1 < len) dst[t + 1] = v[u].y;
