@@ -2120,7 +2120,10 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_validate_more(const KmxIndexDev* 
 // a long survivor list (validate_more_wave).  Lane = list entry while looking for them, then the wave takes the flagged
 // queries one by one.  A kernel of its own so that the registers of the wave-wide paths do not cost the group paths of
 // k_validate_more their occupancy.
-__global__ __launch_bounds__(KMX_BLOCK) void k_validate_wave(const KmxIndexDev* __restrict__ ix,
+#ifndef KMX_VWAVE_OCC
+#define KMX_VWAVE_OCC 4        // waves per SIMD k_validate_wave is compiled for
+#endif
+__global__ __launch_bounds__(KMX_BLOCK, KMX_VWAVE_OCC) void k_validate_wave(const KmxIndexDev* __restrict__ ix,
                                                              const uint32_t* __restrict__ arena,
                                                              const uint8_t* __restrict__ qranks,
                                                              const uint64_t* __restrict__ qoff, QueryDesc d,
