@@ -1677,8 +1677,14 @@ static kmx_status search_finish(kmx_result* r)
             sr.cap_scratch = prefix_elems + 4 * n_large_max;
         }
         const uint64_t cap_items = n_long ? n_long + prefix_elems / KMX_PSORT_BLOCK_CAP + (split_ok ? prefix_elems / kmx::prefix_split_target() + n_large_max : 0) : 0;
-        const uint64_t cap_bands = n_long ? n_long * (KMX_PSORT_BLOCK_CAP / kmx::prefix_band_target() + 1) + prefix_elems / kmx::prefix_band_target() : 0;
-        const uint64_t cap_cuts = std::min<uint64_t>((cap_bands + n_long) * kmx::prefix_band_runs(), uint64_t(1) << 26);
+        // (bands are for slices beyond prefix_band_min() positions — one chunk in the build as it ships: a batch without such slices
+        //  needs no room for bands and no k_prefix_bands launch)
+        const bool chunks_banded = kmx::prefix_band_min() < KMX_PSORT_BLOCK_CAP;
+        const bool bands_possible = !no_bands && n_long && (large || chunks_banded);
+        const uint64_t cap_bands = !bands_possible ? 0
+                                   : chunks_banded ? n_long * (KMX_PSORT_BLOCK_CAP / kmx::prefix_band_target() + 1) + prefix_elems / kmx::prefix_band_target()
+                                                   : prefix_elems / kmx::prefix_band_target() + n_large_max;
+        const uint64_t cap_cuts = std::min<uint64_t>((cap_bands + (chunks_banded ? n_long : n_large_max)) * kmx::prefix_band_runs(), uint64_t(1) << 26);
         if (n_long) {
             HIP_TRY(r->pitems.ensure(cap_items * kmx::prefix_item_bytes()));
             HIP_TRY(r->pbands.ensure(cap_bands * kmx::prefix_item_bytes()));
@@ -1696,7 +1702,7 @@ static kmx_status search_finish(kmx_result* r)
                     sr = kmx::PrefixSplitRoom{};
                 }
             }
-            if (no_bands) HIP_TRY(hipMemsetAsync(r->pbanded.p, 0, np * 4, s));
+            if (!bands_possible && !sr.splits) HIP_TRY(hipMemsetAsync(r->pbanded.p, 0, np * 4, s));
             else {
                 timed(ix, K_PREFIX_BANDS, s, [&] {
                     kmx::launch_prefix_bands(s, dix, qo, d_big, np, hit_off, ix->d_arena, r->pbanded.as<uint32_t>(), r->pbands.p, cap_bands,

@@ -137,6 +137,7 @@ void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64
                               unsigned long long* dbg);
 uint64_t prefix_item_bytes();
 uint64_t prefix_band_target();
+uint64_t prefix_band_min();
 uint64_t prefix_band_runs();
 // one pairwise merge pass over the sorted chunks of the large slices; max_tiles >= tile_off[n_prefix]
 void launch_prefix_merge_pass(hipStream_t s, const QueryDesc& d, uint64_t n_prefix, const uint64_t* tile_off, uint64_t max_tiles,

@@ -4934,6 +4934,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_merge_band(const PsbBand*
 
 uint64_t prefix_item_bytes() { return sizeof(PsbItem); }
 uint64_t prefix_band_target() { return KMX_BAND; }
+uint64_t prefix_band_min() { return KMX_PSORT_BAND_MIN; }
 uint64_t prefix_band_runs() { return KMX_BAND_RUNS; }
 
 // The slices beyond the 256-thread shape that can be cut into bands (few runs, occurrences spread over the text): cut tables and
