@@ -4490,7 +4490,7 @@ __global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_items(const PsbItem*
 //   k_prefix_split_scatter a block per tile again: positions binned by band in LDS, every bin appended to its band in `split`
 // ---------------------------------------------------------------------------
 #ifndef KMX_SPLIT
-#define KMX_SPLIT 24576            // positions per band aimed at (a band takes up to KMX_PSORT_BLOCK_CAP)
+#define KMX_SPLIT 16384            // positions per band aimed at (a band takes up to KMX_PSORT_BLOCK_CAP; 6144 ... 28672 measured: tools/exp/r04_split_target.sh)
 #endif
 #define KMX_SPLIT_MAX 1024         // bands per slice at most (LDS histograms)
 #ifndef KMX_SPLIT_TILE
