@@ -4698,7 +4698,9 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
 //                        KMX_PSORT_MID_CAP positions (a text whose occurrences cluster), nothing: the slice stays with the chunks
 //   k_prefix_merge_band  a block per band: gathers the R run pieces into LDS, merge_runs_lds, leaves coalesced
 // ---------------------------------------------------------------------------
+#ifndef KMX_BAND
 #define KMX_BAND 6144              // positions per band aimed at (a band takes up to KMX_PSORT_MID_CAP: a third of slack for uneven texts)
+#endif
 #define KMX_BAND_RUNS 64           // the 256-thread shape's run capacity
 #define KMX_BAND_MAX 512           // bands per slice at most (their sums live in LDS, a row per wave)
 #ifndef KMX_PSORT_BAND_MIN
