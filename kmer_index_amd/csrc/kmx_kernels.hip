@@ -4698,6 +4698,7 @@ __global__ __launch_bounds__(THREADS) void k_prefix_split_scatter(const PsbSplit
 //                        KMX_PSORT_MID_CAP positions (a text whose occurrences cluster), nothing: the slice stays with the chunks
 //   k_prefix_merge_band  a block per band: gathers the R run pieces into LDS, merge_runs_lds, leaves coalesced
 // ---------------------------------------------------------------------------
+#define KMX_BAND_FULL 7168         // positions per band tried first (7 / 8 of a block's capacity: 6.6 ms against 7.1 on 64 runs of 1526)
 #ifndef KMX_BAND
 #define KMX_BAND 6144              // positions per band aimed at (a band takes up to KMX_PSORT_MID_CAP: a third of slack for uneven texts)
 #endif
@@ -4761,12 +4762,12 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_bands(const KmxIndexDev* _
     const uint32_t q = d.prefix_list[i];
     const uint32_t R = d.c0[q];
     const uint32_t len = d.cnt[q] - uint32_t(__popcll(d.aux[q]));
-    const uint32_t S = (len + KMX_BAND - 1) / KMX_BAND;
+    const uint32_t S_room = (len + KMX_BAND - 1) / KMX_BAND;          // the most bands the slice may be cut into (the caller's room is for these)
     auto leave = [&] { if (lane == 0) banded[i] = 0; };
     // (a slice of one chunk stays a chunk: measured, 24 K positions of 16 runs take a 1024-thread block 5.5 ms per 5e4 slices and their
     //  four bands 5.2 + 1.2 for the cuts — the rounds, not the memory phases, are what both wait for; what the bands save is the
     //  merge passes behind the chunks of a longer slice: 98 K positions of 64 runs 10.1 -> 7.0 ms per 1e4 slices)
-    if (len <= KMX_PSORT_BAND_MIN || R < 2 || R > KMX_BAND_RUNS || S > KMX_BAND_MAX) {
+    if (len <= KMX_PSORT_BAND_MIN || R < 2 || R > KMX_BAND_RUNS || S_room > KMX_BAND_MAX) {
         // too many runs for bands, and more than one chunk: spread by value (k_prefix_split_*) — this wave makes the slice's record, its
         // counters' and its scratch space's places and the list of its tiles
         const uint32_t S2 = (len + KMX_SPLIT - 1) / KMX_SPLIT, n_tiles = (len + KMX_SPLIT_TILE - 1) / KMX_SPLIT_TILE;
@@ -4804,28 +4805,37 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_bands(const KmxIndexDev* _
     }
     // the slice's cut table: rows 0 .. S of R entries (row 0: zeros, row S: the runs' lengths)
     unsigned long long at = 0;
-    if (lane == 0) at = atomicAdd(&used[1], (unsigned long long)(S + 1) * R);
+    if (lane == 0) at = atomicAdd(&used[1], (unsigned long long)(S_room + 1) * R);
     at = __shfl(at, 0);
-    if (at + uint64_t(S + 1) * R > cap_cuts) { leave(); return; }
+    if (at + uint64_t(S_room + 1) * R > cap_cuts) { leave(); return; }
     uint32_t* __restrict__ tab = cuts + at;
     const KMX_GLOBAL uint32_t* offs = prefix_run_bounds(ix, qoff[q + 1] - qoff[q], d.key[q]);       // R + 1 run boundaries
     const uint32_t offs0 = offs[0];
     const uint64_t src0 = d.src[q] & ~SRC_FLAGS, n_text = ix->n;
     const KMX_GLOBAL uint32_t* seg = as_global(arena) + src0;
-    for (uint32_t s = lane; s <= S; s += KMX_WAVE) sums[wv][s] = s == S ? len : 0u;
-    for (uint32_t r = lane; r < R; r += KMX_WAVE) { tab[r] = 0; tab[S * R + r] = offs[r + 1] - offs[r]; }
-    wsync();
-    for (uint32_t p = lane; p < (S - 1) * R; p += KMX_WAVE) {
-        const uint32_t s = 1 + p / R, r = p % R;
-        const uint32_t r_at = offs[r] - offs0, r_len = offs[r + 1] - offs[r];
-        const uint32_t c = band_cut(seg + r_at, r_len, uint32_t((uint64_t(s) * n_text) / S), n_text);
-        tab[s * R + r] = c;
-        atomicAdd(&sums[wv][s], c);
+    // Fuller bands merge faster (a block's rounds cost about the same for 6 K positions as for 7 K): the slice is cut into bands of
+    // KMX_BAND_FULL positions first and, when one of them would not fit a block — occurrences a little uneven over the text —, into
+    // the KMX_BAND ones the room was made for; when those do not fit either the chunks take the slice.
+    uint32_t S = 0;
+    for (uint32_t target = KMX_BAND_FULL; ; target = KMX_BAND) {
+        S = (len + target - 1) / target;
+        for (uint32_t s = lane; s <= S; s += KMX_WAVE) sums[wv][s] = s == S ? len : 0u;
+        for (uint32_t r = lane; r < R; r += KMX_WAVE) { tab[r] = 0; tab[S * R + r] = offs[r + 1] - offs[r]; }
+        wsync();
+        for (uint32_t p = lane; p < (S - 1) * R; p += KMX_WAVE) {
+            const uint32_t s = 1 + p / R, r = p % R;
+            const uint32_t r_at = offs[r] - offs0, r_len = offs[r + 1] - offs[r];
+            const uint32_t c = band_cut(seg + r_at, r_len, uint32_t((uint64_t(s) * n_text) / S), n_text);
+            tab[s * R + r] = c;
+            atomicAdd(&sums[wv][s], c);
+        }
+        wsync();
+        bool fits = true;
+        for (uint32_t s = lane; s < S; s += KMX_WAVE) fits &= sums[wv][s + 1] - sums[wv][s] <= KMX_PSORT_MID_CAP;
+        if (__all(fits)) break;
+        if (target == KMX_BAND) { leave(); return; }                                      // occurrences cluster: the chunks take the slice
+        wsync();                                                                          // (sums[] is rewritten)
     }
-    wsync();
-    bool fits = true;
-    for (uint32_t s = lane; s < S; s += KMX_WAVE) fits &= sums[wv][s + 1] - sums[wv][s] <= KMX_PSORT_MID_CAP;
-    if (!__all(fits)) { leave(); return; }                                                // occurrences cluster: the chunks take the slice
     unsigned long long b_at = 0;
     if (lane == 0) b_at = atomicAdd(&used[0], (unsigned long long)S);
     b_at = __shfl(b_at, 0);
