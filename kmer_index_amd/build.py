@@ -26,7 +26,7 @@ def build(force: bool = False, fill_e: int | None = None, verbose: bool = False,
            "-Wall", "-Wno-unused-result", "-x", "hip"]
     if fill_e:
         cmd.append(f"-DKMX_FILL_E={fill_e}")
-    for knob in ("KMX_PSORT_MULTIWAY_RUNS", "KMX_LOOKUP_OCC", "KMX_PSB_CPT", "KMX_PMERGE_MIN_AVG", "KMX_PMERGE_REG_RUNS", "KMX_PMERGE_REG_LEN", "KMX_PSORT_BAND_MIN", "KMX_SPLIT_TILE", "KMX_SPLIT_SCATTER_THREADS", "KMX_SPLIT", "KMX_NT_QUAD_LOADS", "KMX_PLAIN_QUAD_STORES", "KMX_VWAVE_OCC", "KMX_BAND"):      # tuning experiments only
+    for knob in ("KMX_PSORT_MULTIWAY_RUNS", "KMX_LOOKUP_OCC", "KMX_PSB_CPT", "KMX_PMERGE_MIN_AVG", "KMX_PMERGE_REG_RUNS", "KMX_PMERGE_REG_LEN", "KMX_PSORT_BAND_MIN", "KMX_SPLIT_TILE", "KMX_SPLIT_SCATTER_THREADS", "KMX_SPLIT", "KMX_NT_QUAD_LOADS", "KMX_PLAIN_QUAD_STORES", "KMX_VWAVE_OCC", "KMX_BAND", "KMX_MID_THREADS", "KMX_MID_OCC"):      # tuning experiments only
         if os.environ.get(knob):
             cmd.append(f"-D{knob}={int(os.environ[knob])}")
     if os.environ.get("KMX_PHASE_TIMING"):                                      # measurement build: tools/probe_phases.py

@@ -3885,7 +3885,15 @@ struct PsbShape {
     static constexpr int ROUNDS = RUNS <= 64 ? 6 : 7;        // ceil(log2 RUNS)
 };
 typedef PsbShape<1024, KMX_PSORT_BLOCK_CAP, 128> PsbBig;
-typedef PsbShape<256, KMX_PSORT_MID_CAP, 64> PsbMid;
+#ifndef KMX_MID_THREADS
+#define KMX_MID_THREADS 512    // threads of k_prefix_sort_block (slices up to KMX_PSORT_MID_CAP positions): eight waves per block and SIMD hide the
+#endif                         // merge steps' LDS round trips better than four do (+9 % on 6 K slices; tools/exp/r04_mid_threads.sh)
+#ifndef KMX_MID_OCC
+#define KMX_MID_OCC (KMX_MID_THREADS > 256 ? 8 : 4)
+#endif
+#define KMX_BANDK_THREADS 256  // ... of k_prefix_merge_band (its gather needs the registers: 512 threads measured 3 % slower, 152 B of scratch)
+typedef PsbShape<KMX_MID_THREADS, KMX_PSORT_MID_CAP, 64> PsbMid;
+typedef PsbShape<KMX_BANDK_THREADS, KMX_PSORT_MID_CAP, 64> PsbBandK;
 
 // distribute_sort_lds — the std::sort of kmer_index_result.hpp:258 for a chunk of MORE runs than merge_runs_lds takes (hundreds of
 // short buckets: a sub-k query far below k on an element without prefix levels) whose positions are SPREAD over the text (the
@@ -4147,7 +4155,7 @@ __global__ __launch_bounds__(KMX_BLOCK) void k_prefix_mid_items(const KmxIndexDe
 }
 
 template <int THREADS, int CAP, int RUNS>
-__global__ __launch_bounds__(THREADS, 4) void k_prefix_sort_block(const PsbItem* __restrict__ items, uint64_t n_prefix, uint64_t n_text,
+__global__ __launch_bounds__(THREADS, KMX_MID_OCC) void k_prefix_sort_block(const PsbItem* __restrict__ items, uint64_t n_prefix, uint64_t n_text,
                                                                 const uint32_t* __restrict__ arena, uint32_t* __restrict__ out)
 {
     typedef PsbShape<THREADS, CAP, RUNS> Shape;
@@ -4993,17 +5001,17 @@ void launch_prefix_sort_block(hipStream_t s, const KmxIndexDev* ix, const uint64
     if (n_mid) {
         PsbItem* mi = static_cast<PsbItem*>(mid_items);
         hipLaunchKernelGGL(k_prefix_mid_items, dim3(blocks_for(n_prefix, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qoff, d, n_prefix, hit_off, mi);
-        auto fn = k_prefix_sort_block<256, KMX_PSORT_MID_CAP, 64>;
+        auto fn = k_prefix_sort_block<KMX_MID_THREADS, KMX_PSORT_MID_CAP, 64>;
         const size_t lds = size_t(PsbMid::WORDS) * 4;
         const unsigned int blocks = (unsigned int)std::min<uint64_t>(n_prefix, 256 * 16);
-        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(256), lds, s, mi, n_prefix, n_text, arena, out);
+        hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1, 1), dim3(KMX_MID_THREADS), lds, s, mi, n_prefix, n_text, arena, out);
     }
     if (n_prefix > n_mid) {
         {
-            auto fn = k_prefix_merge_band<256, KMX_PSORT_MID_CAP, KMX_BAND_RUNS>;
-            const size_t lds = size_t(PsbMid::WORDS) * 4;
+            auto fn = k_prefix_merge_band<KMX_BANDK_THREADS, KMX_PSORT_MID_CAP, KMX_BAND_RUNS>;
+            const size_t lds = size_t(PsbBandK::WORDS) * 4;
             const unsigned int blocks = (unsigned int)std::min<uint64_t>(cap_bands, 256 * 16);
-            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(256), lds, s, static_cast<const PsbBand*>(bands), cap_bands, n_bands, cuts, arena, out);
+            hipLaunchKernelGGL(fn, dim3(blocks ? blocks : 1), dim3(KMX_BANDK_THREADS), lds, s, static_cast<const PsbBand*>(bands), cap_bands, n_bands, cuts, arena, out);
         }
         PsbItem* it = static_cast<PsbItem*>(items);
         hipLaunchKernelGGL((k_prefix_items<KMX_PSORT_BLOCK_CAP, 128>), dim3(blocks_for(n_prefix * KMX_WAVE, KMX_BLOCK)), dim3(KMX_BLOCK), 0, s, ix, qoff, d,
